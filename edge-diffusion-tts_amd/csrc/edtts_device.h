@@ -1,0 +1,366 @@
+// edtts_device.h -- device-side building blocks for the gfx950 (MI355X) sampler kernels.
+//
+// Data model ("frame on the lane"):
+//   One wavefront (64 lanes) owns 32 consecutive mel frames of one utterance = two 16-frame tiles (ft = 0, 1).
+//   A [32 x N] activation is held TRANSPOSED in the C/D layout of v_mfma_f32_16x16x4_f32:
+//       reg[nt][ft] (a float4), lane = 16*g + fq  holds  act[frame = 16*ft + fq][feature = 16*nt + 4*g + r], r = 0..3
+//   i.e. frame on (lane & 15), the four lane groups g = lane >> 4 hold different feature quads.
+//   With out^T = W x^T  (A operand = weights [n][k], B operand = activations [k][frame]) the C/D layout of one
+//   GEMM is *exactly* the B-operand layout of the next one when the k index is walked in the order
+//   k = 16*kt + 4*g + r  (MFMA step (kt, r) contracts the four k's {16kt+4g+r : g=0..3}).  Chains of per-frame
+//   linear layers, norms, activations and residuals therefore never leave registers, and the attention
+//   probabilities (C/D of K Q^T) feed the P V product the same way.
+//   Weights are pre-packed (edtts_pack_weights) so that the A fragment of step group (nt, kt) is one float4
+//   per lane, 1 KiB contiguous per wave instruction:  frag[lane] = W[16nt + fq][16kt + 4g + 0..3].
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+#define EDTTS_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+#define EDTTS_DEV __device__ __forceinline__
+
+namespace edtts {
+
+constexpr int kWaveFrames = 32;  // frames per wave
+constexpr int kWavesPerBlock = 4;
+constexpr int kBlockThreads = 64 * kWavesPerBlock;
+constexpr int kBlockFrames = kWaveFrames * kWavesPerBlock;  // 128
+
+template <int H_, int HEADS_, int MEL_>
+struct Cfg {
+  static constexpr int H = H_, HEADS = HEADS_, MEL = MEL_;
+  static constexpr int DH = H / HEADS;            // head dim (40 for the default decoder)
+  static constexpr int DFULL = DH / 16;           // full 16-wide groups of the head dim
+  static constexpr int DREM = DH % 16;            // remainder (0 or 8 supported)
+  static constexpr int DT = (DH + 15) / 16;       // 16-row tiles of the P.V output per head
+  static constexpr int DHP = DT * 16;             // head dim padded to the MFMA tile
+  static constexpr int HT = H / 16;               // feature tiles of the hidden dim
+  static constexpr int MT = MEL / 16;             // feature tiles of the mel dim
+  static constexpr int R = H / 2, RT = R / 16;    // kv_lora_rank (transformer.py:113) and its tiles
+  static constexpr int VR = (HEADS - 1) * DH + DHP;  // rows of a V^T buffer (last head padded)
+  static constexpr int QLD = H + 4;               // LDS row stride (floats) of the cross-attention q tile
+  static_assert(H % 32 == 0 && MEL % 16 == 0 && H % HEADS == 0, "dims");
+  static_assert(DREM == 0 || DREM == 8, "head_dim % 16 must be 0 or 8");
+};
+
+EDTTS_DEV f4 splat(float v) { return f4{v, v, v, v}; }
+EDTTS_DEV f4 ldg4(const float* p) { return *reinterpret_cast<const f4*>(p); }
+EDTTS_DEV f2 ldg2(const float* p) { return *reinterpret_cast<const f2*>(p); }
+EDTTS_DEV void stg4(float* p, f4 v) { *reinterpret_cast<f4*>(p) = v; }
+
+// Correctly rounded fp32 sqrt / divide via fp64 (53 >= 2*24+2 bits, so rounding the fp64 result to fp32 is the
+// IEEE fp32 result) -- the device's fp32 sqrt is not guaranteed correctly rounded, the reference's CPU one is.
+EDTTS_DEV float sqrt_rn(float x) { return (float)sqrt((double)x); }
+EDTTS_DEV float div_rn(float a, float b) { return (float)((double)a / (double)b); }
+
+// reduce a per-lane value over the four lane groups that hold the same frame (lanes fq, fq+16, fq+32, fq+48)
+EDTTS_DEV float group_sum(float v) {
+  v += __shfl_xor(v, 16);
+  v += __shfl_xor(v, 32);
+  return v;
+}
+EDTTS_DEV float group_max(float v) {
+  v = fmaxf(v, __shfl_xor(v, 16));
+  v = fmaxf(v, __shfl_xor(v, 32));
+  return v;
+}
+EDTTS_DEV float hsum(f4 v) { return (v[0] + v[1]) + (v[2] + v[3]); }
+EDTTS_DEV float hmax(f4 v) { return fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])); }
+
+// ---------------------------------------------------------------------------------------------------------
+// Weight fragment stream.  The packed weights of a kernel are laid out in CONSUMPTION order; every phase
+// (one n-tile of an n-major GEMM, or one k-tile of a k-major accumulate) consumes exactly N fragments.
+// The ring holds the next N fragments; using ring[i] immediately re-issues the load for fragment i of the
+// following phase, so the prefetch distance is one whole phase (N float4 loads = N KiB per wave in flight).
+// ---------------------------------------------------------------------------------------------------------
+template <int N>
+struct FragRing {
+  const f4* p;  // lane-offset pointer to the ring's first fragment
+  f4 r[N];
+  EDTTS_DEV void prime(const float* base, int lane) {
+    p = reinterpret_cast<const f4*>(base) + lane;
+#pragma unroll
+    for (int i = 0; i < N; ++i) r[i] = p[i * 64];
+  }
+  // take fragment i of the current phase and prefetch fragment i of the next one
+  EDTTS_DEV f4 take(int i) {
+    f4 a = r[i];
+    r[i] = p[(N + i) * 64];
+    return a;
+  }
+  EDTTS_DEV void advance() { p += N * 64; }
+};
+
+// out^T tile (16 features x 32 frames) = sum_kt frag(kt) * in[kt]:  one n-major phase (N = KT fragments).
+template <int KT>
+EDTTS_DEV void gemm_phase(FragRing<KT>& ring, const f4 (&in)[KT][2], f4& acc0, f4& acc1) {
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt) {
+    f4 a = ring.take(kt);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      acc0 = EDTTS_MFMA(a[r], in[kt][0][r], acc0);
+      acc1 = EDTTS_MFMA(a[r], in[kt][1][r], acc1);
+    }
+  }
+  ring.advance();
+}
+
+// acc[nt] += frag(nt) * in   for one k-tile of a k-major packed matrix (N = NT fragments).
+template <int NT>
+EDTTS_DEV void ktile_phase(FragRing<NT>& ring, f4 in0, f4 in1, f4 (&acc)[NT][2]) {
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    f4 a = ring.take(nt);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      acc[nt][0] = EDTTS_MFMA(a[r], in0[r], acc[nt][0]);
+      acc[nt][1] = EDTTS_MFMA(a[r], in1[r], acc[nt][1]);
+    }
+  }
+  ring.advance();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Norms in the register layout.  x[t][ft] covers features 16t+4g+r of frame (ft, fq).
+// ---------------------------------------------------------------------------------------------------------
+// RMSNorm (layers/mla.py:46-58): x * rsqrt(mean(x^2) + 1e-6) * w ; optional AdaLN modulation
+// (layers/transformer.py:64-68): y * (1 + scale) + shift, with mod = {1+scale [H], shift [H]} rows.
+template <int NT>
+EDTTS_DEV void rms_norm_tile(const f4 (&x)[NT][2], const float* __restrict__ w, const float* __restrict__ mod, int g,
+                             f4 (&y)[NT][2]) {
+  constexpr int N = NT * 16;
+  float ss0 = 0.f, ss1 = 0.f;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    ss0 += hsum(x[t][0] * x[t][0]);
+    ss1 += hsum(x[t][1] * x[t][1]);
+  }
+  const float r0 = rsqrtf(group_sum(ss0) * (1.0f / N) + 1e-6f);
+  const float r1 = rsqrtf(group_sum(ss1) * (1.0f / N) + 1e-6f);
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const f4 wv = ldg4(w + 16 * t + 4 * g);
+    f4 a = x[t][0] * r0 * wv, b = x[t][1] * r1 * wv;
+    if (mod != nullptr) {
+      const f4 sc = ldg4(mod + 16 * t + 4 * g), sh = ldg4(mod + N + 16 * t + 4 * g);
+      a = a * sc + sh;
+      b = b * sc + sh;
+    }
+    y[t][0] = a;
+    y[t][1] = b;
+  }
+}
+
+// LayerNorm(eps 1e-5, affine) (models/decoder.py:59,108)
+template <int NT>
+EDTTS_DEV void layer_norm_tile(const f4 (&x)[NT][2], const float* __restrict__ w, const float* __restrict__ b, int g,
+                               f4 (&y)[NT][2]) {
+  constexpr int N = NT * 16;
+  float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    s0 += hsum(x[t][0]);
+    s1 += hsum(x[t][1]);
+  }
+  const float mu0 = group_sum(s0) * (1.0f / N), mu1 = group_sum(s1) * (1.0f / N);
+  float v0 = 0.f, v1 = 0.f;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const f4 d0 = x[t][0] - mu0, d1 = x[t][1] - mu1;
+    v0 += hsum(d0 * d0);
+    v1 += hsum(d1 * d1);
+  }
+  const float r0 = rsqrtf(group_sum(v0) * (1.0f / N) + 1e-5f), r1 = rsqrtf(group_sum(v1) * (1.0f / N) + 1e-5f);
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const f4 wv = ldg4(w + 16 * t + 4 * g), bv = ldg4(b + 16 * t + 4 * g);
+    y[t][0] = (x[t][0] - mu0) * r0 * wv + bv;
+    y[t][1] = (x[t][1] - mu1) * r1 * wv + bv;
+  }
+}
+
+EDTTS_DEV float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+EDTTS_DEV float silu(float g) { return g / (1.0f + __expf(-g)); }
+
+// ---------------------------------------------------------------------------------------------------------
+// Multi-head attention for one wave's 32 query frames, fused with the output projection:
+//   h += W_o . concat_heads( softmax(q k^T / sqrt(d) [band mask]) v )
+// q comes from global memory (SELF: the q rows written by the previous kernel) or from this wave's LDS tile
+// (cross-attention); K is row-major [key][H]; V is stored transposed [feature][key] so that both MFMA A operands
+// are 16-byte loads.  Scores live only in registers: S^T tile = K Q^T (keys on MFMA rows, queries on lanes), an
+// online softmax over 16-key tiles, and P^T (the C/D registers) is directly the B operand of O^T = V^T P^T.
+// The per-head output tiles O^T[dt] then feed the k-major projection weights from the fragment ring.
+//   SELF : keys are frames of the same utterance, band |i-j| <= window (layers/attention.py:27-30,108-112)
+//   !SELF: keys are the S context tokens, no mask (layers/mla.py:158-179)
+// ---------------------------------------------------------------------------------------------------------
+template <class C, bool SELF, class QLoad>
+EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, const float* __restrict__ VTb, int ldv,
+                               int nkeys, int window, int m0, int lane, FragRing<C::HT>& ring, f4 (&h)[C::HT][2]) {
+  constexpr int DH = C::DH, DFULL = C::DFULL, DREM = C::DREM, DT = C::DT, H = C::H;
+  const int fq = lane & 15, g = lane >> 4;
+  // softmax in base 2: p = 2^((s - m) * c), c = log2(e) / sqrt(d)
+  const float c2 = 1.4426950408889634f * rsqrtf((float)DH);
+  int kt_lo, kt_hi;
+  if (SELF && window >= 0) {
+    const int lo = m0 - window;
+    kt_lo = (lo > 0 ? lo : 0) >> 4;
+    const int hi = m0 + kWaveFrames - 1 + window;  // last key any query of this wave may see
+    const int last = (hi < nkeys - 1 ? hi : nkeys - 1);
+    kt_hi = (last >> 4) + 1;
+  } else {
+    kt_lo = 0;
+    kt_hi = (nkeys + 15) >> 4;
+  }
+  for (int hd = 0; hd < C::HEADS; ++hd) {
+    // ---- q fragments of this head (B operand): lane (fq,g) holds q[query][hd*DH + 16a + 4g + b] -------------
+    f4 qa[2][DFULL > 0 ? DFULL : 1];
+    f2 qr[2];
+#pragma unroll
+    for (int ft = 0; ft < 2; ++ft) {
+#pragma unroll
+      for (int a = 0; a < DFULL; ++a) qa[ft][a] = qload.q4(ft, hd * DH + 16 * a + 4 * g);
+      if (DREM) qr[ft] = qload.q2(ft, hd * DH + 16 * DFULL + 2 * g);
+    }
+    float mrun[2] = {-1e30f, -1e30f}, lrun[2] = {0.f, 0.f};
+    f4 O[DT][2];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) O[dt][0] = O[dt][1] = splat(0.f);
+
+    for (int kt = kt_lo; kt < kt_hi; ++kt) {
+      const int k0 = kt << 4;
+      // A operands: K rows (keys on fq) and V^T rows (head features on fq)
+      const float* kp = Kb + (size_t)(k0 + fq) * H + hd * DH;
+      f4 ka[DFULL > 0 ? DFULL : 1];
+      f2 kr;
+#pragma unroll
+      for (int a = 0; a < DFULL; ++a) ka[a] = ldg4(kp + 16 * a + 4 * g);
+      if (DREM) kr = ldg2(kp + 16 * DFULL + 2 * g);
+      f4 va[DT];
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) va[dt] = ldg4(VTb + (size_t)(hd * DH + 16 * dt + fq) * ldv + k0 + 4 * g);
+
+#pragma unroll
+      for (int ft = 0; ft < 2; ++ft) {
+        const int qi = m0 + 16 * ft + fq;  // this lane's query frame
+        if (SELF && window >= 0) {
+          // skip (wave-uniform) key tiles entirely outside this query tile's band
+          const int q0 = m0 + 16 * ft;
+          if (k0 + 15 < q0 - window || k0 > q0 + 15 + window) continue;
+        }
+        f4 s = splat(0.f);
+#pragma unroll
+        for (int a = 0; a < DFULL; ++a)
+#pragma unroll
+          for (int b = 0; b < 4; ++b) s = EDTTS_MFMA(ka[a][b], qa[ft][a][b], s);
+        if (DREM) {
+          s = EDTTS_MFMA(kr[0], qr[ft][0], s);
+          s = EDTTS_MFMA(kr[1], qr[ft][1], s);
+        }
+        // s[r] = q_qi . k_(k0+4g+r); mask, online softmax
+        bool ok[4];
+        f4 s2;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int kj = k0 + 4 * g + r;
+          bool v = kj < nkeys;
+          if (SELF && window >= 0) {
+            const int d = kj - qi;
+            v = v && (d <= window) && (d >= -window);
+          }
+          ok[r] = v;
+          s2[r] = v ? s[r] * c2 : -1e30f;
+        }
+        const float mx = group_max(hmax(s2));
+        const float mnew = fmaxf(mrun[ft], mx);
+        const float alpha = fast_exp2(mrun[ft] - mnew);
+        mrun[ft] = mnew;
+        f4 p;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) p[r] = ok[r] ? fast_exp2(s2[r] - mnew) : 0.f;
+        lrun[ft] = lrun[ft] * alpha + hsum(p);
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+          f4 o = O[dt][ft] * alpha;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o = EDTTS_MFMA(va[dt][r], p[r], o);
+          O[dt][ft] = o;
+        }
+      }
+    }
+    // ---- normalise and project: h[nt] += Wo[:, head features] . O ------------------------------------------
+#pragma unroll
+    for (int ft = 0; ft < 2; ++ft) {
+      const float lt = group_sum(lrun[ft]);
+      const float inv = lt > 0.f ? 1.0f / lt : 0.f;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) O[dt][ft] *= inv;
+    }
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) ktile_phase<C::HT>(ring, O[dt][0], O[dt][1], h);
+  }
+}
+
+// Elementwise DDIM arithmetic with the reference's operation order and IEEE rounding of every operation
+// (hipcc defaults to -ffp-contract=fast-honor-pragmas: the pragma keeps mul/sub and mul/add unfused).
+EDTTS_DEV void ddim_elem(float x, float e, float s1m, float sab, float sabp, float cdir, float& x0, float& xp) {
+#pragma clang fp contract(off)
+  float t1 = s1m * e;
+  float t2 = x - t1;
+  float v = div_rn(t2, sab);          // schedule.py:189  (x_t - sqrt(1-ab)*eps) / sqrt(ab)
+  v = fminf(fmaxf(v, -3.0f), 3.0f);   // schedule.py:190
+  x0 = v;
+  float t3 = sabp * v;
+  float t4 = cdir * e;                // schedule.py:196  direction uses the raw eps
+  xp = t3 + t4;                       // schedule.py:200
+}
+struct DdimCoef {
+  float s1m, sab, sabp, cdir, sigma;
+};
+EDTTS_DEV DdimCoef ddim_coef(float ab, float abp, float eta) {
+#pragma clang fp contract(off)
+  DdimCoef c;
+  c.s1m = sqrt_rn(1.0f - ab);
+  c.sab = sqrt_rn(ab);
+  float r1 = div_rn(1.0f - abp, 1.0f - ab);
+  float r2 = 1.0f - div_rn(ab, abp);
+  float pr = r1 * r2;
+  c.sigma = eta * sqrt_rn(pr);        // schedule.py:193-195
+  float s2 = c.sigma * c.sigma;
+  float in = 1.0f - abp;
+  in = in - s2;
+  c.cdir = sqrt_rn(in);               // schedule.py:196
+  c.sabp = sqrt_rn(abp);
+  return c;
+}
+EDTTS_DEV float add_mul_rn(float p, float s, float n) {
+#pragma clang fp contract(off)
+  float t = s * n;
+  return p + t;
+}
+
+struct DdpmCoef {
+  float coef1, coef2, sd;
+};
+EDTTS_DEV DdpmCoef ddpm_coef(float al, float ab, float be, float var, bool nonzero) {
+#pragma clang fp contract(off)
+  DdpmCoef c;
+  c.coef1 = div_rn(1.0f, sqrt_rn(al));    // schedule.py:227
+  float om = 1.0f - ab;
+  c.coef2 = div_rn(be, sqrt_rn(om));      // schedule.py:228
+  c.sd = (nonzero ? 1.0f : 0.0f) * sqrt_rn(var);  // mask * sqrt(var), schedule.py:232-237
+  return c;
+}
+EDTTS_DEV float ddpm_elem(float x, float e, float n, DdpmCoef c) {
+#pragma clang fp contract(off)
+  float t1 = c.coef2 * e;
+  float t2 = x - t1;
+  float mean = c.coef1 * t2;
+  float t3 = c.sd * n;
+  return mean + t3;
+}
+
+}  // namespace edtts

@@ -1,0 +1,1122 @@
+// edtts_kernels.hip -- gfx950 kernels + C ABI (include/edtts.h) of the DDIM sampler path.
+//
+// Kernel inventory (all fp32, MFMA = v_mfma_f32_16x16x4_f32, see edtts_device.h for the register data model):
+//   k_pack_gemm / k_copy / k_transpose   weight re-packing into MFMA fragment order (once per weight load)
+//   k_cond        time MLP + step embedding + all AdaLN (1+scale, shift) rows          decoder.py:77-80, transformer.py:64-66
+//   k_ctx         context embedding + per-layer low-rank cross K / V^T cache           decoder.py:83-93, mla.py:143-153
+//   k_prologue    in_proj + positional table, AdaRMSNorm(layer 0), QKV(layer 0)        decoder.py:96-97, attention.py:91-93
+//   k_layer<TAIL> one DiffusionTransformerBlock for a 32-frame wave tile, fully in registers:
+//                 banded self-attention (+proj, residual), RMSNorm + q_proj + cross-attention (+out_proj, residual),
+//                 AdaRMSNorm + SwiGLU FFN (+residual)  (transformer.py:129-160), then the tail:
+//                   TAIL_QKV : AdaRMSNorm + QKV of the NEXT layer
+//                   TAIL_EPS : final LayerNorm + out_proj -> eps                        decoder.py:108-109
+//                   TAIL_DDIM: final LayerNorm + out_proj + DDIM update                 schedule.py:157-202
+//   k_ddim / k_ddpm   standalone elementwise updates (HBM-bound)                       schedule.py:157-238
+//   k_dsconv_*    depthwise-separable Conv1d + GroupNorm + GELU (standalone layer)     conv.py:25-64
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/edtts.h"
+#include "edtts_device.h"
+
+using namespace edtts;
+
+// =========================================================================================================
+// error plumbing
+// =========================================================================================================
+static thread_local char g_err[512] = "";
+static int fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+static int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+#define HIP_TRY(expr)                                                                                   \
+  do {                                                                                                  \
+    hipError_t e_ = (expr);                                                                             \
+    if (e_ != hipSuccess) return fail(EDTTS_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));    \
+  } while (0)
+#define LAUNCH_CHECK(name)                                                                              \
+  do {                                                                                                  \
+    hipError_t e_ = hipGetLastError();                                                                  \
+    if (e_ != hipSuccess) return fail(EDTTS_ERR_HIP, "launch of %s failed: %s", name, hipGetErrorString(e_)); \
+  } while (0)
+
+// =========================================================================================================
+// weight slots
+// =========================================================================================================
+enum GlobalSlot {
+  G_TOK, G_SEMP_W, G_SEMP_B, G_T1_W, G_T1_B, G_T3_W, G_T3_B, G_STEP, G_INP_W, G_INP_B, G_PE, G_CPE, G_FN_W, G_FN_B,
+  G_OUT_W, G_OUT_B, G_FREQS, G_COUNT
+};
+static const char* const kGlobalNames[G_COUNT] = {
+    "token_emb.weight", "sem_proj.weight", "sem_proj.bias", "time_emb.1.weight", "time_emb.1.bias",
+    "time_emb.3.weight", "time_emb.3.bias", "step_emb.weight", "in_proj.weight", "in_proj.bias", "pos_emb.pe",
+    "context_pos_emb.pe", "final_norm.weight", "final_norm.bias", "out_proj.weight", "out_proj.bias", "time_freqs"};
+enum LayerSlot {
+  L_N1_W, L_N1P_W, L_N1P_B, L_QKV_W, L_PROJ_W, L_PROJ_B, L_N2_W, L_QP_W, L_KVD_W, L_KVN_W, L_KVU_W, L_OP_W, L_N3_W,
+  L_N3P_W, L_N3P_B, L_UP_W, L_UP_B, L_DOWN_W, L_DOWN_B, L_COUNT
+};
+static const char* const kLayerNames[L_COUNT] = {
+    "norm1.norm.weight", "norm1.proj.weight", "norm1.proj.bias", "attn.qkv.weight", "attn.proj.weight",
+    "attn.proj.bias", "norm2.weight", "cross_attn.q_proj.weight", "cross_attn.kv_down_proj.weight",
+    "cross_attn.kv_norm.weight", "cross_attn.kv_up_proj.weight", "cross_attn.out_proj.weight", "norm3.norm.weight",
+    "norm3.proj.weight", "norm3.proj.bias", "ffn.net.0.weight", "ffn.net.0.bias", "ffn.net.3.weight",
+    "ffn.net.3.bias"};
+
+// =========================================================================================================
+// packed blob layout (offsets in floats)
+// =========================================================================================================
+constexpr int kMaxLayers = 32;
+struct LayerLayout {
+  size_t n1w, ada1T, ada1b, proj_b, n2w, n3w, ada3T, ada3b, up_b, down_b, kvd, kvn, kvu;
+  size_t s_qkv;   // stream: QKV of this layer            [3HT n-tiles][HT]
+  size_t s_body;  // stream: proj | q_proj | out_proj | ffn   (followed in memory by s_qkv of layer+1 / s_outp)
+};
+struct Layout {
+  int H, HEADS, MEL, L, DH, DHP, HT, MT, R, RT, SD, NTOK, MAXPOS, MAXCPOS, NSTEP;
+  size_t tok, semp, semp_b, t1T, t1b, t3T, t3b, step, inp, inp_b, pe, cpe, fnw, fnb, outp_b, freqs;
+  LayerLayout layer[kMaxLayers];
+  size_t s_outp;  // stream: final out_proj [MT n-tiles][HT]
+  size_t total;
+};
+constexpr size_t kFrag = 256;  // floats per fragment (64 lanes x float4)
+
+static size_t align64(size_t v) { return (v + 63) & ~(size_t)63; }
+
+static int make_layout(const EdttsDims* d, Layout* lo) {
+  if (!d) return fail(EDTTS_ERR_ARG, "dims is NULL");
+  if (d->ffn_mult != 2) return fail(EDTTS_ERR_UNSUPPORTED, "ffn_mult=%d (only 2 is compiled)", d->ffn_mult);
+  if (d->layers < 1 || d->layers > kMaxLayers) return fail(EDTTS_ERR_UNSUPPORTED, "layers=%d out of [1,%d]", d->layers, kMaxLayers);
+  if (d->hidden % 32 || d->n_mels % 16 || d->semantic_dim % 16 || d->heads < 1 || d->hidden % d->heads)
+    return fail(EDTTS_ERR_UNSUPPORTED, "hidden=%d heads=%d n_mels=%d semantic_dim=%d: need hidden%%32==0, n_mels%%16==0, semantic_dim%%16==0",
+                d->hidden, d->heads, d->n_mels, d->semantic_dim);
+  memset(lo, 0, sizeof(*lo));
+  lo->H = d->hidden; lo->HEADS = d->heads; lo->MEL = d->n_mels; lo->L = d->layers;
+  lo->DH = lo->H / lo->HEADS; lo->DHP = (lo->DH + 15) / 16 * 16; lo->HT = lo->H / 16; lo->MT = lo->MEL / 16;
+  lo->R = lo->H / 2; lo->RT = lo->R / 16; lo->SD = d->semantic_dim; lo->NTOK = d->codebook_size;
+  lo->MAXPOS = d->max_pos; lo->MAXCPOS = d->max_ctx_pos; lo->NSTEP = d->n_step_emb;
+  const size_t H = lo->H, HT = lo->HT, MT = lo->MT, R = lo->R, RT = lo->RT, SD = lo->SD;
+  const size_t KPT = (size_t)lo->HEADS * lo->DHP / 16;  // k-tiles of the head-padded projections
+  size_t o = 0;
+  auto take = [&](size_t n) { size_t r = o; o = align64(o + n); return r; };
+  lo->tok = take((size_t)lo->NTOK * H);
+  lo->semp = take(HT * (SD / 16) * kFrag); lo->semp_b = take(H);
+  lo->t1T = take(H * H); lo->t1b = take(H); lo->t3T = take(H * H); lo->t3b = take(H);
+  lo->step = take((size_t)lo->NSTEP * H);
+  lo->inp = take(HT * MT * kFrag); lo->inp_b = take(H);
+  lo->pe = take((size_t)lo->MAXPOS * H); lo->cpe = take((size_t)lo->MAXCPOS * H);
+  lo->fnw = take(H); lo->fnb = take(H); lo->outp_b = take(lo->MEL); lo->freqs = take(H / 2);
+  for (int l = 0; l < lo->L; ++l) {
+    LayerLayout& y = lo->layer[l];
+    y.n1w = take(H); y.ada1T = take(H * 2 * H); y.ada1b = take(2 * H); y.proj_b = take(H); y.n2w = take(H);
+    y.n3w = take(H); y.ada3T = take(H * 2 * H); y.ada3b = take(2 * H); y.up_b = take(4 * H); y.down_b = take(H);
+    y.kvd = take(RT * HT * kFrag); y.kvn = take(R); y.kvu = take(2 * HT * RT * kFrag);
+  }
+  // contiguous fragment stream: qkv(0) body(0) qkv(1) body(1) ... body(L-1) outp  + one ring of slack
+  for (int l = 0; l < lo->L; ++l) {
+    LayerLayout& y = lo->layer[l];
+    y.s_qkv = o; o += 3 * HT * HT * kFrag;
+    y.s_body = o; o += (KPT * HT /*proj*/ + HT * HT /*q_proj*/ + KPT * HT /*out_proj*/ + 2 * HT * 3 * HT /*ffn*/) * kFrag;
+  }
+  lo->s_outp = o; o += MT * HT * kFrag;
+  o += HT * kFrag;  // the ring prefetches one phase past the last consumed fragment
+  lo->total = align64(o);
+  return EDTTS_OK;
+}
+
+// =========================================================================================================
+// packing kernels
+// =========================================================================================================
+struct PackArgs {
+  const float* src;
+  int ld, N, K;      // source row stride, logical rows / cols
+  int NT, KT;        // packed tile counts
+  int rowmode;       // 0 identity, 1 ffn-up interleave (tile 2j = value rows 16j.., tile 2j+1 = gate rows N/2+16j..)
+  int colmode;       // 0 identity, 1 head padding (packed col hd*DHP+dd <- hd*DH+dd, zero for dd >= DH)
+  int dstmode;       // 0 n-major, 1 k-major, 2 ffn-up inside the ffn stream, 3 ffn-down inside the ffn stream
+  int DH, DHP;
+  float* dst;
+};
+__global__ void k_pack_gemm(PackArgs a) {
+  const int tile = blockIdx.x, lane = threadIdx.x;
+  const int nt = tile / a.KT, kt = tile % a.KT;
+  const int fq = lane & 15, g = lane >> 4;
+  int n = 16 * nt + fq, row;
+  bool rok;
+  if (a.rowmode == 1) {
+    const int j = nt >> 1, gate = nt & 1;
+    row = gate * (a.N / 2) + 16 * j + fq;
+    rok = true;
+  } else {
+    row = n;
+    rok = n < a.N;
+  }
+  f4 v;
+  for (int r = 0; r < 4; ++r) {
+    const int k = 16 * kt + 4 * g + r;
+    int col = k;
+    bool cok = k < a.K;
+    if (a.colmode == 1) {
+      const int hd = k / a.DHP, dd = k % a.DHP;
+      cok = dd < a.DH;
+      col = hd * a.DH + dd;
+    }
+    v[r] = (rok && cok) ? a.src[(size_t)row * a.ld + col] : 0.f;
+  }
+  size_t frag;
+  const int S3 = 2 * a.KT + a.NT;  // fragments per ffn hidden tile (valid when KT == NT == HT for mode 2; see host)
+  switch (a.dstmode) {
+    case 0: frag = (size_t)nt * a.KT + kt; break;
+    case 1: frag = (size_t)kt * a.NT + nt; break;
+    case 2: frag = (size_t)(nt >> 1) * (3 * a.KT) + (nt & 1) * a.KT + kt; break;        // up: [j][val KT | gate KT | down NT]
+    default: frag = (size_t)kt * (3 * a.NT) + 2 * a.NT + nt; break;                       // down: k-tile kt = hidden tile j
+  }
+  (void)S3;
+  stg4(a.dst + (frag * 64 + lane) * 4, v);
+}
+__global__ void k_copy(const float* src, float* dst, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = src[i];
+}
+// dst[k][n] = src[n][k]   (src [N][K])
+__global__ void k_transpose(const float* src, float* dst, int N, int K) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < (size_t)N * K) {
+    int k = (int)(i / N), n = (int)(i % N);
+    dst[i] = src[(size_t)n * K + k];
+  }
+}
+// ffn up bias in stream order: [j][value 16 | gate 16]
+__global__ void k_pack_upbias(const float* src, float* dst, int H2 /* = 2H hidden */) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < 2 * H2) {
+    int j = i / 32, w = i % 32;
+    dst[i] = (w < 16) ? src[16 * j + w] : src[H2 + 16 * j + (w - 16)];
+  }
+}
+
+// =========================================================================================================
+// conditioning kernel: one block per (t, step_idx) row
+// =========================================================================================================
+constexpr int kMaxHostRows = 32;
+struct CondArgs {
+  const int64_t* t;         // device rows, or null -> t_host / step_host (by-value, graph-capturable)
+  const int64_t* step_idx;  // may be null
+  int use_host, host_has_step;
+  int t_host[kMaxHostRows], step_host[kMaxHostRows];
+  int H, L, n_step;
+  const float *freqs, *t1T, *t1b, *t3T, *t3b, *step;
+  const float* blob;
+  unsigned ada1T[kMaxLayers], ada1b[kMaxLayers], ada3T[kMaxLayers], ada3b[kMaxLayers];  // offsets (floats) -- blob < 16 GiB
+  float* cond;  // [rows][L][2][2H]
+};
+__global__ __launch_bounds__(256) void k_cond(CondArgs a) {
+  extern __shared__ float sm[];
+  float* e = sm;            // [H] sinusoidal embedding
+  float* u = sm + a.H;      // [H] hidden of the MLP
+  float* c = sm + 2 * a.H;  // [H] t_cond
+  const int row = blockIdx.x, tid = threadIdx.x, H = a.H, half = H / 2;
+  const float tf = a.use_host ? (float)a.t_host[row] : (float)a.t[row];
+  for (int j = tid; j < H; j += blockDim.x) {
+    const float arg = tf * a.freqs[j < half ? j : j - half];  // embeddings.py:42
+    e[j] = j < half ? sinf(arg) : cosf(arg);                  // cat[sin, cos], embeddings.py:43
+  }
+  __syncthreads();
+  for (int n = tid; n < H; n += blockDim.x) {
+    float acc = a.t1b[n];
+    for (int k = 0; k < H; ++k) acc = fmaf(e[k], a.t1T[(size_t)k * H + n], acc);
+    u[n] = 0.5f * acc * (1.0f + erff(acc * 0.70710678118654752440f));  // exact GELU (decoder.py:29)
+  }
+  __syncthreads();
+  long sidx = -1;
+  if (a.use_host ? a.host_has_step : (a.step_idx != nullptr)) {
+    sidx = a.use_host ? (long)a.step_host[row] : (long)a.step_idx[row];
+    sidx = sidx < 0 ? 0 : (sidx >= a.n_step ? a.n_step - 1 : sidx);  // the reference raises IndexError (F7); clamp, never fault
+  }
+  for (int n = tid; n < H; n += blockDim.x) {
+    float acc = a.t3b[n];
+    for (int k = 0; k < H; ++k) acc = fmaf(u[k], a.t3T[(size_t)k * H + n], acc);
+    if (sidx >= 0) acc += a.step[(size_t)sidx * H + n];
+    c[n] = acc;
+  }
+  __syncthreads();
+  for (int l = 0; l < a.L; ++l) {
+    for (int which = 0; which < 2; ++which) {
+      const float* WT = a.blob + (which ? a.ada3T[l] : a.ada1T[l]);
+      const float* bb = a.blob + (which ? a.ada3b[l] : a.ada1b[l]);
+      float* out = a.cond + (((size_t)row * a.L + l) * 2 + which) * 2 * H;
+      for (int n = tid; n < 2 * H; n += blockDim.x) {
+        float acc = bb[n];
+        for (int k = 0; k < H; ++k) acc = fmaf(c[k], WT[(size_t)k * 2 * H + n], acc);
+        out[n] = n < H ? 1.0f + acc : acc;  // first half = scale (stored as 1+scale), second = shift
+      }
+    }
+  }
+}
+
+// =========================================================================================================
+// shared kernel argument block
+// =========================================================================================================
+struct KArgs {
+  int B, T, Tp, S, Sp, window, max_pos, max_cpos, n_tok, SD, L;
+  // inputs / outputs
+  const float* x;  // [B][T][MEL]
+  float *h, *q, *k, *vT;
+  float *kc, *vcT;  // cross K / V^T cache: kernel-specific base (k_ctx: whole cache; k_layer: this layer's slice)
+  const int64_t* sem_idx;
+  const float* sem_feat;
+  const float* cond;  // row base: [L][2][2H] per row
+  int cond_bstride;   // floats between batch rows (0 = one row shared by the batch)
+  int layer;
+  // weights
+  const float *tok, *semp, *semp_b, *cpe, *inp, *inp_b, *pe;
+  const float *n1w, *proj_b, *n2w, *n3w, *up_b, *down_b, *fnw, *fnb, *outp_b;
+  const float* stream;
+  // tail outputs
+  float *eps, *x_prev, *x0;
+  float c_s1m, c_sab, c_sabp, c_dir;
+};
+
+// block -> wave tile mapping with an XCD-aware remap: the hardware deals consecutive block ids round-robin over the 8
+// XCDs; remapping gives every XCD a contiguous range of frame tiles, so the K/V halo rows a tile shares with its
+// neighbours are served by that XCD's L2 (speed only; correctness does not depend on placement).
+EDTTS_DEV int remap_block(int bid, int nblk) {
+  const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+  const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + idx;
+}
+
+struct TileId {
+  int b, m0;
+  bool valid;
+};
+EDTTS_DEV TileId wave_tile(int B, int Tp) {
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int tpu = Tp / kWaveFrames;
+  const int w = remap_block(blockIdx.x, gridDim.x) * kWavesPerBlock + wave;
+  TileId t;
+  t.valid = w < B * tpu;
+  t.b = w / tpu;
+  t.m0 = (w - t.b * tpu) * kWaveFrames;
+  return t;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// QKV of one layer from the normalised tile hn: stores q, k row-major [B][Tp][H] and v transposed [B][VR][Tp]
+// (layers/attention.py:91-93: rows of qkv.weight are q | k | v, each head-major)
+// ---------------------------------------------------------------------------------------------------------
+template <class C>
+EDTTS_DEV void qkv_tail(FragRing<C::HT>& ring, const f4 (&hn)[C::HT][2], const KArgs& a, int b, int m0, int lane) {
+  const int fq = lane & 15, g = lane >> 4;
+  const size_t rowbase = (size_t)b * a.Tp + m0 + fq;
+  for (int which = 0; which < 3; ++which) {
+    for (int nt = 0; nt < C::HT; ++nt) {
+      f4 a0 = splat(0.f), a1 = splat(0.f);
+      gemm_phase<C::HT>(ring, hn, a0, a1);
+      if (which < 2) {
+        float* dst = (which == 0 ? a.q : a.k) + rowbase * C::H + 16 * nt + 4 * g;
+        stg4(dst, a0);
+        stg4(dst + 16 * C::H, a1);
+      } else {
+        float* dst = a.vT + ((size_t)b * C::VR + 16 * nt + 4 * g) * a.Tp + m0 + fq;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          dst[(size_t)r * a.Tp] = a0[r];
+          dst[(size_t)r * a.Tp + 16] = a1[r];
+        }
+      }
+    }
+  }
+}
+
+// =========================================================================================================
+// prologue: h = in_proj(x) + pe ; AdaRMSNorm(layer 0) ; QKV(layer 0)
+// =========================================================================================================
+template <class C>
+__global__ __launch_bounds__(kBlockThreads) void k_prologue(KArgs a) {
+  const TileId tl = wave_tile(a.B, a.Tp);
+  if (!tl.valid) return;
+  const int lane = threadIdx.x & 63, fq = lane & 15, g = lane >> 4;
+  const int b = tl.b, m0 = tl.m0;
+  f4 xin[C::MT][2];
+#pragma unroll
+  for (int ft = 0; ft < 2; ++ft) {
+    const int f = m0 + 16 * ft + fq;
+#pragma unroll
+    for (int t = 0; t < C::MT; ++t)
+      xin[t][ft] = f < a.T ? ldg4(a.x + ((size_t)b * a.T + f) * C::MEL + 16 * t + 4 * g) : splat(0.f);
+  }
+  f4 h[C::HT][2];
+  const f4* wp = reinterpret_cast<const f4*>(a.inp) + lane;
+#pragma unroll
+  for (int nt = 0; nt < C::HT; ++nt) {
+    const f4 bias = ldg4(a.inp_b + 16 * nt + 4 * g);
+#pragma unroll
+    for (int ft = 0; ft < 2; ++ft) {
+      int f = m0 + 16 * ft + fq;
+      f = f < a.max_pos ? f : a.max_pos - 1;
+      h[nt][ft] = bias + ldg4(a.pe + (size_t)f * C::H + 16 * nt + 4 * g);  // embeddings.py:142
+    }
+#pragma unroll
+    for (int kt = 0; kt < C::MT; ++kt) {
+      const f4 w = wp[(nt * C::MT + kt) * 64];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        h[nt][0] = EDTTS_MFMA(w[r], xin[kt][0][r], h[nt][0]);
+        h[nt][1] = EDTTS_MFMA(w[r], xin[kt][1][r], h[nt][1]);
+      }
+    }
+  }
+  FragRing<C::HT> ring;
+  ring.prime(a.stream, lane);
+  {
+    float* hp = a.h + ((size_t)b * a.Tp + m0 + fq) * C::H + 4 * g;
+#pragma unroll
+    for (int nt = 0; nt < C::HT; ++nt) {
+      stg4(hp + 16 * nt, h[nt][0]);
+      stg4(hp + 16 * nt + 16 * C::H, h[nt][1]);
+    }
+  }
+  f4 hn[C::HT][2];
+  const float* mod = a.cond + (size_t)b * a.cond_bstride;  // layer 0, norm1
+  rms_norm_tile<C::HT>(h, a.n1w, mod, g, hn);
+  qkv_tail<C>(ring, hn, a, b, m0, lane);
+}
+
+// =========================================================================================================
+// transformer layer kernel
+// =========================================================================================================
+enum { TAIL_QKV = 0, TAIL_EPS = 1, TAIL_DDIM = 2 };
+
+struct QGlobal {  // q rows in global memory, row-major [Tp][H]
+  const float* base;  // row of query frame (ft = 0, fq)
+  int H;
+  EDTTS_DEV f4 q4(int ft, int col) const { return ldg4(base + (size_t)ft * 16 * H + col); }
+  EDTTS_DEV f2 q2(int ft, int col) const { return ldg2(base + (size_t)ft * 16 * H + col); }
+};
+struct QLds {  // q tile in this wave's LDS region, [32][QLD]
+  const float* base;  // row fq
+  int ld;
+  EDTTS_DEV f4 q4(int ft, int col) const { return *reinterpret_cast<const f4*>(base + ft * 16 * ld + col); }
+  EDTTS_DEV f2 q2(int ft, int col) const { return *reinterpret_cast<const f2*>(base + ft * 16 * ld + col); }
+};
+
+template <class C, int TAIL>
+__global__ __launch_bounds__(kBlockThreads) void k_layer(KArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const TileId tl = wave_tile(a.B, a.Tp);
+  if (!tl.valid) return;
+  const int lane = threadIdx.x & 63, fq = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int b = tl.b, m0 = tl.m0;
+  float* qtile = smem + (size_t)wave * kWaveFrames * C::QLD;
+  const size_t rowbase = (size_t)b * a.Tp + m0 + fq;
+
+  FragRing<C::HT> ring;
+  ring.prime(a.stream, lane);
+
+  // residual stream tile, + self-attention projection bias (attention.py:123)
+  f4 h[C::HT][2];
+  {
+    const float* hp = a.h + rowbase * C::H + 4 * g;
+#pragma unroll
+    for (int nt = 0; nt < C::HT; ++nt) {
+      const f4 pb = ldg4(a.proj_b + 16 * nt + 4 * g);
+      h[nt][0] = ldg4(hp + 16 * nt) + pb;
+      h[nt][1] = ldg4(hp + 16 * nt + 16 * C::H) + pb;
+    }
+  }
+  // ---- x = x + attn(norm1(x, cond))   (transformer.py:142-146; q/k/v were produced by the previous kernel) ----
+  {
+    QGlobal ql{a.q + rowbase * C::H, C::H};
+    attention_fused<C, true>(ql, a.k + (size_t)b * a.Tp * C::H, a.vT + (size_t)b * C::VR * a.Tp, a.Tp, a.T, a.window, m0,
+                             lane, ring, h);
+  }
+  // ---- x = x + cross_attn(norm2(x), context)   (transformer.py:151, mla.py:118-194) --------------------------
+  {
+    f4 hn[C::HT][2];
+    rms_norm_tile<C::HT>(h, a.n2w, nullptr, g, hn);
+    for (int nt = 0; nt < C::HT; ++nt) {
+      f4 a0 = splat(0.f), a1 = splat(0.f);
+      gemm_phase<C::HT>(ring, hn, a0, a1);
+      stg4(qtile + fq * C::QLD + 16 * nt + 4 * g, a0);
+      stg4(qtile + (16 + fq) * C::QLD + 16 * nt + 4 * g, a1);
+    }
+  }
+  {
+    QLds ql{qtile + fq * C::QLD, C::QLD};
+    attention_fused<C, false>(ql, a.kc + (size_t)b * a.Sp * C::H, a.vcT + (size_t)b * C::VR * a.Sp, a.Sp, a.S, -1, m0, lane,
+                              ring, h);
+  }
+  // ---- x = x + ffn(norm3(x, cond))   (transformer.py:154-158, :13-49) ----------------------------------------
+  {
+    f4 hn[C::HT][2];
+    const float* mod = a.cond + (size_t)b * a.cond_bstride + ((size_t)a.layer * 2 + 1) * 2 * C::H;
+    rms_norm_tile<C::HT>(h, a.n3w, mod, g, hn);
+#pragma unroll
+    for (int nt = 0; nt < C::HT; ++nt) {
+      const f4 db = ldg4(a.down_b + 16 * nt + 4 * g);
+      h[nt][0] += db;
+      h[nt][1] += db;
+    }
+    for (int j = 0; j < 2 * C::HT; ++j) {
+      const f4 vb = ldg4(a.up_b + 32 * j + 4 * g), gb = ldg4(a.up_b + 32 * j + 16 + 4 * g);
+      f4 v0 = vb, v1 = vb, g0 = gb, g1 = gb;
+      gemm_phase<C::HT>(ring, hn, v0, v1);
+      gemm_phase<C::HT>(ring, hn, g0, g1);
+      f4 act0, act1;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        act0[r] = v0[r] * silu(g0[r]);  // SwiGLU: value * silu(gate), transformer.py:21-23
+        act1[r] = v1[r] * silu(g1[r]);
+      }
+      ktile_phase<C::HT>(ring, act0, act1, h);
+    }
+  }
+  // ---- tail ---------------------------------------------------------------------------------------------------
+  if (TAIL == TAIL_QKV) {
+    float* hp = a.h + rowbase * C::H + 4 * g;
+#pragma unroll
+    for (int nt = 0; nt < C::HT; ++nt) {
+      stg4(hp + 16 * nt, h[nt][0]);
+      stg4(hp + 16 * nt + 16 * C::H, h[nt][1]);
+    }
+    f4 hn[C::HT][2];
+    const float* mod = a.cond + (size_t)b * a.cond_bstride + ((size_t)(a.layer + 1) * 2) * 2 * C::H;
+    rms_norm_tile<C::HT>(h, a.n1w, mod, g, hn);
+    qkv_tail<C>(ring, hn, a, b, m0, lane);
+  } else {
+    f4 hn[C::HT][2];
+    layer_norm_tile<C::HT>(h, a.fnw, a.fnb, g, hn);
+#pragma unroll
+    for (int nt = 0; nt < C::MT; ++nt) {
+      const f4 ob = ldg4(a.outp_b + 16 * nt + 4 * g);
+      f4 e0 = ob, e1 = ob;
+      gemm_phase<C::HT>(ring, hn, e0, e1);
+#pragma unroll
+      for (int ft = 0; ft < 2; ++ft) {
+        const int f = m0 + 16 * ft + fq;
+        if (f >= a.T) continue;
+        const size_t idx = ((size_t)b * a.T + f) * C::MEL + 16 * nt + 4 * g;
+        const f4 e = ft ? e1 : e0;
+        if (TAIL == TAIL_EPS) {
+          stg4(a.eps + idx, e);
+        } else {
+          // DDIM update, same operation order as schedule.py:189-199 (no fma contraction)
+          const f4 xv = ldg4(a.x + idx);
+          f4 x0, xp;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float v0, vp;
+            ddim_elem(xv[r], e[r], a.c_s1m, a.c_sab, a.c_sabp, a.c_dir, v0, vp);
+            x0[r] = v0;
+            xp[r] = vp;
+          }
+          stg4(a.x0 + idx, x0);
+          stg4(a.x_prev + idx, xp);
+        }
+      }
+    }
+  }
+}
+
+// =========================================================================================================
+// context kernel: ctx = token_emb[sem_idx] (or sem_proj(features)) + pe_ctx ; per layer K / V^T cache
+// =========================================================================================================
+struct CtxArgs {
+  int B, S, Sp, L, SD, n_tok, max_cpos;
+  const int64_t* sem_idx;
+  const float* sem_feat;
+  const float *tok, *semp, *semp_b, *cpe;
+  const float* blob;
+  unsigned kvd[kMaxLayers], kvn[kMaxLayers], kvu[kMaxLayers];
+  float *kc, *vcT;  // [L][B][Sp][H], [L][B][VR][Sp]
+};
+template <class C>
+__global__ __launch_bounds__(kBlockThreads) void k_ctx(CtxArgs a) {
+  const TileId tl = wave_tile(a.B, a.Sp);
+  if (!tl.valid) return;
+  const int lane = threadIdx.x & 63, fq = lane & 15, g = lane >> 4;
+  const int b = tl.b, m0 = tl.m0;
+  f4 ctx[C::HT][2];
+  if (a.sem_feat != nullptr) {
+    // context = sem_proj(sem_features)   (decoder.py:83-85)
+    const int KT = a.SD / 16;
+    const f4* wp = reinterpret_cast<const f4*>(a.semp) + lane;
+#pragma unroll
+    for (int nt = 0; nt < C::HT; ++nt) ctx[nt][0] = ctx[nt][1] = ldg4(a.semp_b + 16 * nt + 4 * g);
+    for (int kt = 0; kt < KT; ++kt) {
+      f4 xin[2];
+#pragma unroll
+      for (int ft = 0; ft < 2; ++ft) {
+        const int s = m0 + 16 * ft + fq;
+        xin[ft] = s < a.S ? ldg4(a.sem_feat + ((size_t)b * a.S + s) * a.SD + 16 * kt + 4 * g) : splat(0.f);
+      }
+#pragma unroll
+      for (int nt = 0; nt < C::HT; ++nt) {
+        const f4 w = wp[(nt * KT + kt) * 64];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          ctx[nt][0] = EDTTS_MFMA(w[r], xin[0][r], ctx[nt][0]);
+          ctx[nt][1] = EDTTS_MFMA(w[r], xin[1][r], ctx[nt][1]);
+        }
+      }
+    }
+  } else {
+#pragma unroll
+    for (int ft = 0; ft < 2; ++ft) {
+      const int s = m0 + 16 * ft + fq;
+      long tk = s < a.S ? (long)a.sem_idx[(size_t)b * a.S + s] : 0;
+      tk = tk < 0 ? 0 : (tk >= a.n_tok ? a.n_tok - 1 : tk);  // nn.Embedding would raise; clamp, never fault
+      const float* row = a.tok + (size_t)tk * C::H + 4 * g;
+#pragma unroll
+      for (int nt = 0; nt < C::HT; ++nt) ctx[nt][ft] = ldg4(row + 16 * nt);  // decoder.py:88
+    }
+  }
+#pragma unroll
+  for (int ft = 0; ft < 2; ++ft) {
+    int s = m0 + 16 * ft + fq;
+    s = s < a.max_cpos ? s : a.max_cpos - 1;
+    const float* row = a.cpe + (size_t)s * C::H + 4 * g;
+#pragma unroll
+    for (int nt = 0; nt < C::HT; ++nt) ctx[nt][ft] += ldg4(row + 16 * nt);  // decoder.py:93
+  }
+  for (int l = 0; l < a.L; ++l) {
+    // c = RMSNorm_R(kv_down(ctx))   (mla.py:144-145)
+    f4 c[C::RT][2];
+    {
+      FragRing<C::HT> ring;
+      ring.prime(a.blob + a.kvd[l], lane);
+#pragma unroll
+      for (int nt = 0; nt < C::RT; ++nt) {
+        c[nt][0] = c[nt][1] = splat(0.f);
+        gemm_phase<C::HT>(ring, ctx, c[nt][0], c[nt][1]);
+      }
+    }
+    f4 cn[C::RT][2];
+    rms_norm_tile<C::RT>(c, a.blob + a.kvn[l], nullptr, g, cn);
+    // kv = kv_up(c): first H outputs = K, second H = V   (mla.py:150-153)
+    FragRing<C::RT> ring;
+    ring.prime(a.blob + a.kvu[l], lane);
+    float* kdst = a.kc + (((size_t)l * a.B + b) * a.Sp + m0 + fq) * C::H + 4 * g;
+    float* vdst = a.vcT + (((size_t)l * a.B + b) * C::VR + 4 * g) * a.Sp + m0 + fq;
+    for (int nt = 0; nt < 2 * C::HT; ++nt) {
+      f4 a0 = splat(0.f), a1 = splat(0.f);
+      gemm_phase<C::RT>(ring, cn, a0, a1);
+      if (nt < C::HT) {
+        stg4(kdst + 16 * nt, a0);
+        stg4(kdst + 16 * nt + 16 * C::H, a1);
+      } else {
+        float* d = vdst + (size_t)(16 * (nt - C::HT)) * a.Sp;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          d[(size_t)r * a.Sp] = a0[r];
+          d[(size_t)r * a.Sp + 16] = a1[r];
+        }
+      }
+    }
+  }
+}
+
+// =========================================================================================================
+// standalone DDIM / DDPM updates (HBM-bound: read x, eps ; write x_prev, x0 = 16 B/element)
+// =========================================================================================================
+struct StepArgs {
+  const float *alphas, *alpha_bar, *betas, *post_var;
+  int n_table;
+  const float *x, *eps, *noise;
+  const int64_t *t, *t_prev;
+  size_t n_per_batch;
+  float eta;
+  float *x_prev, *x0;
+};
+EDTTS_DEV long clamp_idx(long v, int n) { return v < 0 ? 0 : (v >= n ? n - 1 : v); }
+
+__global__ __launch_bounds__(256) void k_ddim(StepArgs a) {
+  const int b = blockIdx.y;
+  // per-batch scalars, evaluated with the reference's operation sequence (schedule.py:179-196)
+  const float ab = a.alpha_bar[clamp_idx((long)a.t[b], a.n_table)];
+  const long tp = (long)a.t_prev[b];
+  const float abp = tp >= 0 ? a.alpha_bar[clamp_idx(tp, a.n_table)] : 1.0f;
+  const DdimCoef cf = ddim_coef(ab, abp, a.eta);
+  const float s1m = cf.s1m, sab = cf.sab, sabp = cf.sabp, cdir = cf.cdir, sigma = cf.sigma;
+  const size_t base = (size_t)b * a.n_per_batch;
+  const size_t n4 = a.n_per_batch >> 2;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t o = base + 4 * i;
+    const f4 xv = ldg4(a.x + o), e = ldg4(a.eps + o);
+    f4 nz = splat(0.f);
+    if (a.noise) nz = ldg4(a.noise + o);
+    f4 x0, xp;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float v, p;
+      ddim_elem(xv[r], e[r], s1m, sab, sabp, cdir, v, p);
+      if (a.noise) p = add_mul_rn(p, sigma, nz[r]);
+      x0[r] = v;
+      xp[r] = p;
+    }
+    stg4(a.x0 + o, x0);
+    stg4(a.x_prev + o, xp);
+  }
+  // ragged tail (n_per_batch % 4) -- never hit for n_mels % 4 == 0, kept for generality
+  if (blockIdx.x == 0 && threadIdx.x < (a.n_per_batch & 3)) {
+    const size_t o = base + (n4 << 2) + threadIdx.x;
+    float v, p;
+    ddim_elem(a.x[o], a.eps[o], s1m, sab, sabp, cdir, v, p);
+    if (a.noise) p = add_mul_rn(p, sigma, a.noise[o]);
+    a.x0[o] = v;
+    a.x_prev[o] = p;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_ddpm(StepArgs a) {
+  const int b = blockIdx.y;
+  const long tt = clamp_idx((long)a.t[b], a.n_table);
+  const float al = a.alphas[tt], ab = a.alpha_bar[tt], be = a.betas[tt];
+  const DdpmCoef cf = ddpm_coef(al, ab, be, a.post_var[tt], (long)a.t[b] > 0);
+  const size_t base = (size_t)b * a.n_per_batch;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n_per_batch; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t o = base + i;
+    a.x_prev[o] = ddpm_elem(a.x[o], a.eps[o], a.noise[o], cf);
+  }
+}
+
+// =========================================================================================================
+// depthwise-separable conv (standalone exported layer, conv.py:25-64) -- simple, not on the timed path
+// =========================================================================================================
+// z[b][co][t] = pb[co] + sum_ci pw[co][ci] * (sum_j dw[ci][j] * x[b][ci][t + j - k/2])
+__global__ void k_dsconv_pw(const float* x, const float* dw, const float* pw, const float* pb, int B, int Ci, int Co, int T,
+                            int ks, float* z) {
+  extern __shared__ float dsm[];  // depthwise output tile [Ci][64]
+  const int b = blockIdx.y, t0 = blockIdx.x * 64, pad = ks / 2;
+  for (int i = threadIdx.x; i < Ci * 64; i += blockDim.x) {
+    const int ci = i / 64, tt = t0 + (i % 64);
+    float acc = 0.f;
+    if (tt < T)
+      for (int j = 0; j < ks; ++j) {
+        const int ts = tt + j - pad;
+        if (ts >= 0 && ts < T) acc = fmaf(x[((size_t)b * Ci + ci) * T + ts], dw[ci * ks + j], acc);
+      }
+    dsm[i] = acc;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < Co * 64; i += blockDim.x) {
+    const int co = i / 64, tl = i % 64;
+    if (t0 + tl >= T) continue;
+    float acc = pb[co];
+    for (int ci = 0; ci < Ci; ++ci) acc = fmaf(pw[(size_t)co * Ci + ci], dsm[ci * 64 + tl], acc);
+    z[((size_t)b * Co + co) * T + t0 + tl] = acc;
+  }
+}
+// per (b, group) mean / rstd over (Co/groups)*T elements (two-pass, deterministic)
+__global__ void k_dsconv_stats(const float* z, int Co, int T, int groups, float* stats) {
+  __shared__ float red[256];
+  const int bg = blockIdx.x, n = (Co / groups) * T;
+  const float* p = z + (size_t)bg * n;  // groups are contiguous channel ranges
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) s += p[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if (threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+    __syncthreads();
+  }
+  const float mu = red[0] / n;
+  __syncthreads();
+  float v = 0.f;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const float d = p[i] - mu;
+    v += d * d;
+  }
+  red[threadIdx.x] = v;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if (threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    stats[2 * bg] = mu;
+    stats[2 * bg + 1] = rsqrtf(red[0] / n + 1e-5f);
+  }
+}
+__global__ void k_dsconv_norm(const float* z, const float* stats, const float* gw, const float* gb, int Co, int T, int groups,
+                              size_t total, float* y) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int co = (int)((i / T) % Co);
+  const size_t b = i / ((size_t)T * Co);
+  const int cpg = Co / groups;
+  const size_t bg = b * groups + co / cpg;
+  const float v = (z[i] - stats[2 * bg]) * stats[2 * bg + 1] * gw[co] + gb[co];
+  y[i] = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+}
+
+// =========================================================================================================
+// host side
+// =========================================================================================================
+struct Workspace {
+  size_t h, q, k, vT, kc, vcT, cond, total;  // offsets in floats
+  int Tp, Sp, VR;
+};
+static void make_workspace(const Layout& lo, int B, int T, int S, int cond_rows, Workspace* w) {
+  const size_t H = lo.H;
+  w->Tp = (T + kWaveFrames - 1) / kWaveFrames * kWaveFrames;
+  w->Sp = (S + kWaveFrames - 1) / kWaveFrames * kWaveFrames;
+  w->VR = (lo.HEADS - 1) * lo.DH + lo.DHP;
+  size_t o = 0;
+  auto take = [&](size_t n) { size_t r = o; o = align64(o + n); return r; };
+  w->h = take((size_t)B * w->Tp * H);
+  w->q = take((size_t)B * w->Tp * H);
+  w->k = take((size_t)B * w->Tp * H);
+  w->vT = take((size_t)B * w->VR * w->Tp);
+  w->kc = take((size_t)lo.L * B * w->Sp * H);
+  w->vcT = take((size_t)lo.L * B * w->VR * w->Sp);
+  w->cond = take((size_t)cond_rows * lo.L * 2 * 2 * H);
+  w->total = o;
+}
+
+template <class C>
+struct Launcher {
+  static size_t layer_lds() { return (size_t)kWavesPerBlock * kWaveFrames * C::QLD * sizeof(float); }
+  static int grid(int B, int Tp) { return (B * (Tp / kWaveFrames) + kWavesPerBlock - 1) / kWavesPerBlock; }
+
+  static int ctx(const Layout& lo, const float* blob, const Workspace& ws, float* wsb, int B, int S, const int64_t* sem_idx,
+                 const float* sem_feat, hipStream_t st) {
+    CtxArgs a;
+    memset(&a, 0, sizeof(a));
+    a.B = B; a.S = S; a.Sp = ws.Sp; a.L = lo.L; a.SD = lo.SD; a.n_tok = lo.NTOK; a.max_cpos = lo.MAXCPOS;
+    a.sem_idx = sem_idx; a.sem_feat = sem_feat;
+    a.tok = blob + lo.tok; a.semp = blob + lo.semp; a.semp_b = blob + lo.semp_b; a.cpe = blob + lo.cpe; a.blob = blob;
+    for (int l = 0; l < lo.L; ++l) {
+      a.kvd[l] = (unsigned)lo.layer[l].kvd; a.kvn[l] = (unsigned)lo.layer[l].kvn; a.kvu[l] = (unsigned)lo.layer[l].kvu;
+    }
+    a.kc = wsb + ws.kc; a.vcT = wsb + ws.vcT;
+    hipLaunchKernelGGL(k_ctx<C>, dim3(grid(B, ws.Sp)), dim3(kBlockThreads), 0, st, a);
+    LAUNCH_CHECK("k_ctx");
+    return EDTTS_OK;
+  }
+
+  static void base_args(const Layout& lo, const float* blob, const Workspace& ws, float* wsb, int B, int T, int S,
+                        int window, KArgs* a) {
+    memset(a, 0, sizeof(*a));
+    a->B = B; a->T = T; a->Tp = ws.Tp; a->S = S; a->Sp = ws.Sp; a->window = window; a->max_pos = lo.MAXPOS;
+    a->max_cpos = lo.MAXCPOS; a->n_tok = lo.NTOK; a->SD = lo.SD; a->L = lo.L;
+    a->h = wsb + ws.h; a->q = wsb + ws.q; a->k = wsb + ws.k; a->vT = wsb + ws.vT;
+    a->inp = blob + lo.inp; a->inp_b = blob + lo.inp_b; a->pe = blob + lo.pe;
+    a->fnw = blob + lo.fnw; a->fnb = blob + lo.fnb; a->outp_b = blob + lo.outp_b;
+  }
+
+  // one decoder forward given conditioning rows + context cache already in the workspace
+  static int forward(const Layout& lo, const float* blob, const Workspace& ws, float* wsb, int B, int T, int S, int window,
+                     const float* x, const float* cond_row, int cond_bstride, int tail, float* eps, float* x_prev, float* x0,
+                     const float* coef, hipStream_t st) {
+    KArgs a;
+    base_args(lo, blob, ws, wsb, B, T, S, window, &a);
+    a.x = x; a.cond = cond_row; a.cond_bstride = cond_bstride;
+    const int g = grid(B, ws.Tp);
+    a.n1w = blob + lo.layer[0].n1w; a.stream = blob + lo.layer[0].s_qkv; a.layer = 0;
+    hipLaunchKernelGGL(k_prologue<C>, dim3(g), dim3(kBlockThreads), 0, st, a);
+    LAUNCH_CHECK("k_prologue");
+    for (int l = 0; l < lo.L; ++l) {
+      const LayerLayout& y = lo.layer[l];
+      a.layer = l;
+      a.proj_b = blob + y.proj_b; a.n2w = blob + y.n2w; a.n3w = blob + y.n3w; a.up_b = blob + y.up_b;
+      a.down_b = blob + y.down_b; a.stream = blob + y.s_body;
+      a.kc = wsb + ws.kc + (size_t)l * B * ws.Sp * lo.H;
+      a.vcT = wsb + ws.vcT + (size_t)l * B * ws.VR * ws.Sp;
+      if (l + 1 < lo.L) {
+        a.n1w = blob + lo.layer[l + 1].n1w;
+        hipLaunchKernelGGL((k_layer<C, TAIL_QKV>), dim3(g), dim3(kBlockThreads), layer_lds(), st, a);
+      } else if (tail == TAIL_EPS) {
+        a.eps = eps;
+        hipLaunchKernelGGL((k_layer<C, TAIL_EPS>), dim3(g), dim3(kBlockThreads), layer_lds(), st, a);
+      } else {
+        a.x_prev = x_prev; a.x0 = x0;
+        a.c_s1m = coef[0]; a.c_sab = coef[1]; a.c_sabp = coef[2]; a.c_dir = coef[3];
+        hipLaunchKernelGGL((k_layer<C, TAIL_DDIM>), dim3(g), dim3(kBlockThreads), layer_lds(), st, a);
+      }
+      LAUNCH_CHECK("k_layer");
+    }
+    return EDTTS_OK;
+  }
+
+  static int set_attrs() {
+    // kernels with > 64 KiB of dynamic LDS need the opt-in attribute
+    static bool done = false;
+    if (done) return EDTTS_OK;
+    const int lds = (int)layer_lds();
+    HIP_TRY(hipFuncSetAttribute((const void*)k_layer<C, TAIL_QKV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    HIP_TRY(hipFuncSetAttribute((const void*)k_layer<C, TAIL_EPS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    HIP_TRY(hipFuncSetAttribute((const void*)k_layer<C, TAIL_DDIM>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    done = true;
+    return EDTTS_OK;
+  }
+};
+
+// compiled decoder shapes: (hidden, heads, n_mels)
+#define EDTTS_DISPATCH(lo, CALL)                                                                         \
+  do {                                                                                                   \
+    if ((lo).H == 160 && (lo).HEADS == 4 && (lo).MEL == 80) { using C = Cfg<160, 4, 80>; CALL; }          \
+    else if ((lo).H == 256 && (lo).HEADS == 8 && (lo).MEL == 80) { using C = Cfg<256, 8, 80>; CALL; }     \
+    else if ((lo).H == 32 && (lo).HEADS == 2 && (lo).MEL == 80) { using C = Cfg<32, 2, 80>; CALL; }       \
+    else if ((lo).H == 64 && (lo).HEADS == 4 && (lo).MEL == 16) { using C = Cfg<64, 4, 16>; CALL; }       \
+    else return fail(EDTTS_ERR_UNSUPPORTED, "no kernel instance for hidden=%d heads=%d n_mels=%d "        \
+                     "(compiled: 160/4/80, 256/8/80, 32/2/80, 64/4/16)", (lo).H, (lo).HEADS, (lo).MEL);   \
+  } while (0)
+
+static int launch_cond(const Layout& lo, const float* blob, const int64_t* t, const int64_t* step_idx, const int64_t* t_host,
+                       int rows, float* cond, hipStream_t st) {
+  CondArgs a;
+  memset(&a, 0, sizeof(a));
+  a.t = t; a.step_idx = step_idx; a.H = lo.H; a.L = lo.L; a.n_step = lo.NSTEP;
+  if (t_host) {  // fused sampler: row i = (timesteps[i], step index i), inference.py:38-40
+    if (rows > kMaxHostRows) return fail(EDTTS_ERR_ARG, "num_steps=%d > %d", rows, kMaxHostRows);
+    a.use_host = 1; a.host_has_step = 1;
+    for (int i = 0; i < rows; ++i) { a.t_host[i] = (int)t_host[i]; a.step_host[i] = i; }
+  }
+  a.freqs = blob + lo.freqs; a.t1T = blob + lo.t1T; a.t1b = blob + lo.t1b; a.t3T = blob + lo.t3T; a.t3b = blob + lo.t3b;
+  a.step = blob + lo.step; a.blob = blob;
+  for (int l = 0; l < lo.L; ++l) {
+    a.ada1T[l] = (unsigned)lo.layer[l].ada1T; a.ada1b[l] = (unsigned)lo.layer[l].ada1b;
+    a.ada3T[l] = (unsigned)lo.layer[l].ada3T; a.ada3b[l] = (unsigned)lo.layer[l].ada3b;
+  }
+  a.cond = cond;
+  hipLaunchKernelGGL(k_cond, dim3(rows), dim3(256), 3 * lo.H * sizeof(float), st, a);
+  LAUNCH_CHECK("k_cond");
+  return EDTTS_OK;
+}
+
+extern "C" {
+
+int edtts_version(void) { return EDTTS_VERSION; }
+const char* edtts_last_error(void) { return g_err; }
+int edtts_num_global_slots(void) { return G_COUNT; }
+int edtts_num_layer_slots(void) { return L_COUNT; }
+const char* edtts_global_slot_name(int i) { return (i >= 0 && i < G_COUNT) ? kGlobalNames[i] : nullptr; }
+const char* edtts_layer_slot_name(int i) { return (i >= 0 && i < L_COUNT) ? kLayerNames[i] : nullptr; }
+
+int edtts_packed_bytes(const EdttsDims* dims, size_t* out_bytes) {
+  Layout lo;
+  int rc = make_layout(dims, &lo);
+  if (rc) return rc;
+  if (!out_bytes) return fail(EDTTS_ERR_ARG, "out_bytes is NULL");
+  if (lo.total >= ((size_t)1 << 32)) return fail(EDTTS_ERR_UNSUPPORTED, "packed blob too large");
+  *out_bytes = lo.total * sizeof(float);
+  return EDTTS_OK;
+}
+
+int edtts_workspace_bytes(const EdttsDims* dims, int B, int T, int S, int cond_rows, size_t* out_bytes) {
+  Layout lo;
+  int rc = make_layout(dims, &lo);
+  if (rc) return rc;
+  if (!out_bytes || B < 1 || T < 1 || S < 1 || cond_rows < 1) return fail(EDTTS_ERR_ARG, "bad workspace query (B=%d T=%d S=%d rows=%d)", B, T, S, cond_rows);
+  Workspace w;
+  make_workspace(lo, B, T, S, cond_rows, &w);
+  *out_bytes = w.total * sizeof(float);
+  return EDTTS_OK;
+}
+
+static int pack_gemm(hipStream_t st, const float* src, int ld, int N, int K, int NT, int KT, int rowmode, int colmode,
+                     int dstmode, int DH, int DHP, float* dst) {
+  PackArgs p{src, ld, N, K, NT, KT, rowmode, colmode, dstmode, DH, DHP, dst};
+  hipLaunchKernelGGL(k_pack_gemm, dim3(NT * KT), dim3(64), 0, st, p);
+  LAUNCH_CHECK("k_pack_gemm");
+  return EDTTS_OK;
+}
+static int copy_f(hipStream_t st, const float* src, float* dst, size_t n) {
+  hipLaunchKernelGGL(k_copy, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, dst, n);
+  LAUNCH_CHECK("k_copy");
+  return EDTTS_OK;
+}
+static int transpose_f(hipStream_t st, const float* src, float* dst, int N, int K) {
+  hipLaunchKernelGGL(k_transpose, dim3((unsigned)(((size_t)N * K + 255) / 256)), dim3(256), 0, st, src, dst, N, K);
+  LAUNCH_CHECK("k_transpose");
+  return EDTTS_OK;
+}
+#define TRY(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
+
+int edtts_pack_weights(const EdttsDims* dims, const void* const* slots, int n_slots, void* packed, void* stream) {
+  Layout lo;
+  TRY(make_layout(dims, &lo));
+  if (!slots || !packed) return fail(EDTTS_ERR_ARG, "slots/packed is NULL");
+  if (n_slots != G_COUNT + lo.L * L_COUNT) return fail(EDTTS_ERR_ARG, "expected %d weight slots, got %d", G_COUNT + lo.L * L_COUNT, n_slots);
+  for (int i = 0; i < n_slots; ++i)
+    if (!slots[i]) return fail(EDTTS_ERR_ARG, "weight slot %d is NULL", i);
+  hipStream_t st = (hipStream_t)stream;
+  float* blob = (float*)packed;
+  auto G = [&](int i) { return (const float*)slots[i]; };
+  const int H = lo.H, HT = lo.HT, MT = lo.MT, R = lo.R, RT = lo.RT, SD = lo.SD, DH = lo.DH, DHP = lo.DHP;
+  const int KPT = lo.HEADS * DHP / 16;
+  HIP_TRY(hipMemsetAsync(blob, 0, lo.total * sizeof(float), st));
+  TRY(copy_f(st, G(G_TOK), blob + lo.tok, (size_t)lo.NTOK * H));
+  TRY(pack_gemm(st, G(G_SEMP_W), SD, H, SD, HT, SD / 16, 0, 0, 0, DH, DHP, blob + lo.semp));
+  TRY(copy_f(st, G(G_SEMP_B), blob + lo.semp_b, H));
+  TRY(transpose_f(st, G(G_T1_W), blob + lo.t1T, H, H));
+  TRY(copy_f(st, G(G_T1_B), blob + lo.t1b, H));
+  TRY(transpose_f(st, G(G_T3_W), blob + lo.t3T, H, H));
+  TRY(copy_f(st, G(G_T3_B), blob + lo.t3b, H));
+  TRY(copy_f(st, G(G_STEP), blob + lo.step, (size_t)lo.NSTEP * H));
+  TRY(pack_gemm(st, G(G_INP_W), lo.MEL, H, lo.MEL, HT, MT, 0, 0, 0, DH, DHP, blob + lo.inp));
+  TRY(copy_f(st, G(G_INP_B), blob + lo.inp_b, H));
+  TRY(copy_f(st, G(G_PE), blob + lo.pe, (size_t)lo.MAXPOS * H));
+  TRY(copy_f(st, G(G_CPE), blob + lo.cpe, (size_t)lo.MAXCPOS * H));
+  TRY(copy_f(st, G(G_FN_W), blob + lo.fnw, H));
+  TRY(copy_f(st, G(G_FN_B), blob + lo.fnb, H));
+  TRY(pack_gemm(st, G(G_OUT_W), H, lo.MEL, H, MT, HT, 0, 0, 0, DH, DHP, blob + lo.s_outp));
+  TRY(copy_f(st, G(G_OUT_B), blob + lo.outp_b, lo.MEL));
+  TRY(copy_f(st, G(G_FREQS), blob + lo.freqs, H / 2));
+  for (int l = 0; l < lo.L; ++l) {
+    const LayerLayout& y = lo.layer[l];
+    auto W = [&](int i) { return (const float*)slots[G_COUNT + l * L_COUNT + i]; };
+    TRY(copy_f(st, W(L_N1_W), blob + y.n1w, H));
+    TRY(transpose_f(st, W(L_N1P_W), blob + y.ada1T, 2 * H, H));
+    TRY(copy_f(st, W(L_N1P_B), blob + y.ada1b, 2 * H));
+    TRY(copy_f(st, W(L_PROJ_B), blob + y.proj_b, H));
+    TRY(copy_f(st, W(L_N2_W), blob + y.n2w, H));
+    TRY(copy_f(st, W(L_N3_W), blob + y.n3w, H));
+    TRY(transpose_f(st, W(L_N3P_W), blob + y.ada3T, 2 * H, H));
+    TRY(copy_f(st, W(L_N3P_B), blob + y.ada3b, 2 * H));
+    hipLaunchKernelGGL(k_pack_upbias, dim3((4 * H + 255) / 256), dim3(256), 0, st, W(L_UP_B), blob + y.up_b, 2 * H);
+    LAUNCH_CHECK("k_pack_upbias");
+    TRY(copy_f(st, W(L_DOWN_B), blob + y.down_b, H));
+    TRY(pack_gemm(st, W(L_KVD_W), H, R, H, RT, HT, 0, 0, 0, DH, DHP, blob + y.kvd));
+    TRY(copy_f(st, W(L_KVN_W), blob + y.kvn, R));
+    TRY(pack_gemm(st, W(L_KVU_W), R, 2 * H, R, 2 * HT, RT, 0, 0, 0, DH, DHP, blob + y.kvu));
+    // fragment stream
+    TRY(pack_gemm(st, W(L_QKV_W), H, 3 * H, H, 3 * HT, HT, 0, 0, 0, DH, DHP, blob + y.s_qkv));
+    float* s = blob + y.s_body;
+    TRY(pack_gemm(st, W(L_PROJ_W), H, H, lo.HEADS * DHP, HT, KPT, 0, 1, 1, DH, DHP, s));
+    s += (size_t)KPT * HT * kFrag;
+    TRY(pack_gemm(st, W(L_QP_W), H, H, H, HT, HT, 0, 0, 0, DH, DHP, s));
+    s += (size_t)HT * HT * kFrag;
+    TRY(pack_gemm(st, W(L_OP_W), H, H, lo.HEADS * DHP, HT, KPT, 0, 1, 1, DH, DHP, s));
+    s += (size_t)KPT * HT * kFrag;
+    TRY(pack_gemm(st, W(L_UP_W), H, 4 * H, H, 4 * HT, HT, 1, 0, 2, DH, DHP, s));       // value/gate tiles interleaved
+    TRY(pack_gemm(st, W(L_DOWN_W), 2 * H, H, 2 * H, HT, 2 * HT, 0, 0, 3, DH, DHP, s));  // k-tile j after its up tiles
+  }
+  return EDTTS_OK;
+}
+
+static int check_shapes(const Layout& lo, int B, int T, int S) {
+  if (B < 1 || T < 1 || S < 1) return fail(EDTTS_ERR_ARG, "B=%d T=%d S=%d must be positive", B, T, S);
+  if (T > lo.MAXPOS) return fail(EDTTS_ERR_ARG, "T=%d exceeds the positional table (%d rows) -- the reference raises here too", T, lo.MAXPOS);
+  if (S > lo.MAXCPOS) return fail(EDTTS_ERR_ARG, "S=%d exceeds the context positional table (%d rows)", S, lo.MAXCPOS);
+  return EDTTS_OK;
+}
+
+int edtts_decoder_forward(const EdttsDims* dims, const void* packed, void* workspace, int B, int T, int S, const float* x,
+                          const int64_t* t, const int64_t* step_idx, const int64_t* sem_idx, const float* sem_features,
+                          float* eps, void* stream) {
+  Layout lo;
+  TRY(make_layout(dims, &lo));
+  if (!sem_idx && !sem_features) return fail(EDTTS_ERR_ARG, "Either sem_idx or sem_features must be provided");
+  if (!packed || !workspace || !x || !t || !eps) return fail(EDTTS_ERR_ARG, "NULL pointer argument");
+  TRY(check_shapes(lo, B, T, S));
+  hipStream_t st = (hipStream_t)stream;
+  const float* blob = (const float*)packed;
+  float* wsb = (float*)workspace;
+  Workspace ws;
+  make_workspace(lo, B, T, S, B, &ws);
+  TRY(launch_cond(lo, blob, t, step_idx, nullptr, B, wsb + ws.cond, st));
+  const int bstride = lo.L * 2 * 2 * lo.H;
+  EDTTS_DISPATCH(lo, {
+    TRY(Launcher<C>::set_attrs());
+    TRY(Launcher<C>::ctx(lo, blob, ws, wsb, B, S, sem_features ? nullptr : sem_idx, sem_features, st));
+    TRY(Launcher<C>::forward(lo, blob, ws, wsb, B, T, S, dims->window, x, wsb + ws.cond, bstride, TAIL_EPS, eps, nullptr,
+                             nullptr, nullptr, st));
+  });
+  return EDTTS_OK;
+}
+
+int edtts_generate(const EdttsDims* dims, const void* packed, void* workspace, int B, int S, const int64_t* sem_idx,
+                   const float* x_T, int num_steps, const int64_t* timesteps_host, const float* coef_host, float* x_work,
+                   float* x0_out, void* stream) {
+  Layout lo;
+  TRY(make_layout(dims, &lo));
+  if (!packed || !workspace || !sem_idx || !x_T || !timesteps_host || !coef_host || !x_work || !x0_out)
+    return fail(EDTTS_ERR_ARG, "NULL pointer argument");
+  if (num_steps < 1 || num_steps > lo.NSTEP)
+    return fail(EDTTS_ERR_ARG, "num_steps=%d outside [1,%d] (step_emb rows; the reference raises IndexError)", num_steps, lo.NSTEP);
+  const int T = 2 * S;  // inference.py:31
+  TRY(check_shapes(lo, B, T, S));
+  hipStream_t st = (hipStream_t)stream;
+  const float* blob = (const float*)packed;
+  float* wsb = (float*)workspace;
+  Workspace ws;
+  make_workspace(lo, B, T, S, num_steps, &ws);
+  TRY(launch_cond(lo, blob, nullptr, nullptr, timesteps_host, num_steps, wsb + ws.cond, st));
+  const size_t row = (size_t)lo.L * 2 * 2 * lo.H;
+  EDTTS_DISPATCH(lo, {
+    TRY(Launcher<C>::set_attrs());
+    TRY(Launcher<C>::ctx(lo, blob, ws, wsb, B, S, sem_idx, nullptr, st));
+    for (int i = 0; i < num_steps; ++i) {
+      const float* xin = (i == 0) ? x_T : x_work;
+      TRY(Launcher<C>::forward(lo, blob, ws, wsb, B, T, S, dims->window, xin, wsb + ws.cond + i * row, 0, TAIL_DDIM, nullptr,
+                               x_work, x0_out, coef_host + 4 * i, st));
+    }
+  });
+  return EDTTS_OK;
+}
+
+int edtts_ddim_step(const float* alpha_bar, int n_table, const float* x, const float* eps, const int64_t* t,
+                    const int64_t* t_prev, int B, size_t n_per_batch, float eta, const float* noise, float* x_prev, float* x0,
+                    void* stream) {
+  if (!alpha_bar || !x || !eps || !t || !t_prev || !x_prev || !x0) return fail(EDTTS_ERR_ARG, "NULL pointer argument");
+  if (eta > 0.f && !noise) return fail(EDTTS_ERR_ARG, "eta > 0 needs a noise tensor");
+  if (B < 1 || n_per_batch < 1 || n_table < 1) return fail(EDTTS_ERR_ARG, "bad sizes");
+  StepArgs a;
+  memset(&a, 0, sizeof(a));
+  a.alpha_bar = alpha_bar; a.n_table = n_table; a.x = x; a.eps = eps; a.t = t; a.t_prev = t_prev;
+  a.n_per_batch = n_per_batch; a.eta = eta; a.noise = eta > 0.f ? noise : nullptr; a.x_prev = x_prev; a.x0 = x0;
+  size_t bx = (n_per_batch / 4 + 255) / 256;
+  if (bx > 2048) bx = 2048;
+  if (bx < 1) bx = 1;
+  hipLaunchKernelGGL(k_ddim, dim3((unsigned)bx, B), dim3(256), 0, (hipStream_t)stream, a);
+  LAUNCH_CHECK("k_ddim");
+  return EDTTS_OK;
+}
+
+int edtts_ddpm_step(const float* alphas, const float* alpha_bar, const float* betas, const float* post_var, int n_table,
+                    const float* x, const float* eps, const int64_t* t, int B, size_t n_per_batch, const float* noise,
+                    float* x_prev, void* stream) {
+  if (!alphas || !alpha_bar || !betas || !post_var || !x || !eps || !t || !noise || !x_prev) return fail(EDTTS_ERR_ARG, "NULL pointer argument");
+  if (B < 1 || n_per_batch < 1 || n_table < 1) return fail(EDTTS_ERR_ARG, "bad sizes");
+  StepArgs a;
+  memset(&a, 0, sizeof(a));
+  a.alphas = alphas; a.alpha_bar = alpha_bar; a.betas = betas; a.post_var = post_var; a.n_table = n_table;
+  a.x = x; a.eps = eps; a.t = t; a.n_per_batch = n_per_batch; a.noise = noise; a.x_prev = x_prev;
+  size_t bx = (n_per_batch + 255) / 256;
+  if (bx > 2048) bx = 2048;
+  hipLaunchKernelGGL(k_ddpm, dim3((unsigned)bx, B), dim3(256), 0, (hipStream_t)stream, a);
+  LAUNCH_CHECK("k_ddpm");
+  return EDTTS_OK;
+}
+
+int edtts_dsconv_forward(const float* x, const float* dw, const float* pw, const float* pb, const float* gn_w, const float* gn_b,
+                         int B, int C_in, int C_out, int T, int ksize, int groups, float* scratch, float* y, void* stream) {
+  if (!x || !dw || !pw || !pb || !gn_w || !gn_b || !scratch || !y) return fail(EDTTS_ERR_ARG, "NULL pointer argument");
+  if (B < 1 || C_in < 1 || C_out < 1 || T < 1 || ksize < 1 || groups < 1 || C_out % groups) return fail(EDTTS_ERR_ARG, "bad sizes");
+  if ((size_t)C_in * 64 * sizeof(float) > 64 * 1024) return fail(EDTTS_ERR_UNSUPPORTED, "C_in=%d too large for the LDS tile", C_in);
+  hipStream_t st = (hipStream_t)stream;
+  float* z = scratch;
+  float* stats = scratch + (size_t)B * C_out * T;
+  hipLaunchKernelGGL(k_dsconv_pw, dim3((T + 63) / 64, B), dim3(256), (size_t)C_in * 64 * sizeof(float), st, x, dw, pw, pb, B, C_in,
+                     C_out, T, ksize, z);
+  LAUNCH_CHECK("k_dsconv_pw");
+  hipLaunchKernelGGL(k_dsconv_stats, dim3(B * groups), dim3(256), 0, st, z, C_out, T, groups, stats);
+  LAUNCH_CHECK("k_dsconv_stats");
+  const size_t total = (size_t)B * C_out * T;
+  hipLaunchKernelGGL(k_dsconv_norm, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, z, stats, gn_w, gn_b, C_out, T, groups,
+                     total, y);
+  LAUNCH_CHECK("k_dsconv_norm");
+  return EDTTS_OK;
+}
+
+}  // extern "C"

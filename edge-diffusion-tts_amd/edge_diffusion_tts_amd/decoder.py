@@ -1,0 +1,145 @@
+"""EdgeDiffusionDecoder -- API mirror of /root/reference/edge_diffusion_tts/models/decoder.py:14-109 on MI355X.
+
+The module owns parameters and buffers under the reference's state-dict key names, so
+``load_state_dict(reference_decoder.state_dict())`` works, but it has no sub-module forward code: ``forward`` hands
+device pointers to the C ABI (include/edtts.h, edtts_decoder_forward) where the whole network runs as hand-written
+gfx950 kernels.  Inference only (the reference path this replaces runs under ``torch.no_grad``, inference.py:23);
+dropout is the identity as in ``decoder.eval()``.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import native
+from .synth import decoder_shapes, sinusoidal_table, time_frequencies
+
+
+class _Node(nn.Module):
+    """Parameter container; the tree of _Node objects reproduces the reference's dotted key names."""
+
+
+def _attach(root: nn.Module, key: str, tensor: torch.Tensor, is_buffer: bool) -> None:
+    *path, leaf = key.split(".")
+    mod = root
+    for name in path:
+        if name not in mod._modules:
+            mod.add_module(name, _Node())
+        mod = mod._modules[name]
+    if is_buffer:
+        mod.register_buffer(leaf, tensor)
+    else:
+        mod.register_parameter(leaf, nn.Parameter(tensor, requires_grad=False))
+
+
+class EdgeDiffusionDecoder(nn.Module):
+    def __init__(self, cfg, max_len: int = 1000, max_context_len: int = 512):
+        """``max_len`` / ``max_context_len`` size the two sinusoidal tables (reference: 1000 / 512, decoder.py:38,41);
+        they are pure functions of position, so larger values only lift the reference's length limit."""
+        super().__init__()
+        self.cfg = cfg
+        self.max_len, self.max_context_len, self.n_step_emb = int(max_len), int(max_context_len), 16
+        H = cfg.hidden
+        for key, shape in decoder_shapes(cfg, self.max_len, self.max_context_len, self.n_step_emb).items():
+            if key == "pos_emb.pe":
+                _attach(self, key, sinusoidal_table(self.max_len, H), True)
+            elif key == "context_pos_emb.pe":
+                _attach(self, key, sinusoidal_table(self.max_context_len, H), True)
+            else:
+                _attach(self, key, self._default_init(key, shape), False)
+        self._fix_bias_init()
+        self.register_buffer("_time_freqs", time_frequencies(H), persistent=False)
+        self._packed: Optional[torch.Tensor] = None
+        self._packed_sig: Optional[Tuple] = None
+        self._workspaces: Dict[Tuple, torch.Tensor] = {}
+
+    # same distributions as the reference's default construction (nn.Linear / nn.Embedding defaults, ones for norm
+    # gains, zeros for final out_proj and the AdaLN projections -- decoder.py:63-64, transformer.py:61-62)
+    @staticmethod
+    def _default_init(key: str, shape) -> torch.Tensor:
+        leaf = key.rsplit(".", 1)[-1]
+        if key.startswith("out_proj.") or ".norm1.proj." in key or ".norm3.proj." in key:
+            return torch.zeros(shape)
+        if key.endswith("emb.weight"):
+            return torch.randn(shape)
+        if "norm" in key and leaf == "weight" and len(shape) == 1:
+            return torch.ones(shape)
+        if key == "final_norm.bias":
+            return torch.zeros(shape)
+        if leaf == "weight":
+            bound = 1.0 / math.sqrt(shape[-1])
+            return torch.empty(shape).uniform_(-bound, bound)
+        return torch.zeros(shape)  # Linear biases: drawn in _fix_bias_init (needs the sibling weight's fan-in)
+
+    def _fix_bias_init(self) -> None:
+        sd = dict(self.named_parameters())
+        for k, p in sd.items():
+            if k.endswith(".bias") and not (k.startswith("out_proj.") or ".norm1.proj." in k or ".norm3.proj." in k or k == "final_norm.bias"):
+                w = sd[k[:-4] + "weight"]
+                bound = 1.0 / math.sqrt(w.shape[-1])
+                with torch.no_grad():
+                    p.uniform_(-bound, bound)
+
+    def reset_parameters(self) -> None:
+        self._fix_bias_init()
+
+    # ------------------------------------------------------------------------------------------ native state
+    def dims(self) -> native.EdttsDims:
+        c = self.cfg
+        window = -1 if c.attn_window_size is None else int(c.attn_window_size)
+        return native.EdttsDims(c.hidden, c.layers, c.heads, c.n_mels, c.ffn_mult, c.codebook_size, c.semantic_dim, window,
+                                self.max_len, self.max_context_len, self.n_step_emb)
+
+    def _state_tensors(self) -> Dict[str, torch.Tensor]:
+        sd = {k: v for k, v in self.named_parameters()}
+        sd.update({k: v for k, v in self.named_buffers()})
+        sd["time_freqs"] = sd.pop("_time_freqs")
+        return sd
+
+    def _ensure_packed(self) -> torch.Tensor:
+        sd = self._state_tensors()
+        names = native.slot_names(self.cfg.layers)
+        tensors = [sd[n] for n in names]
+        sig = tuple((t.data_ptr(), t._version) for t in tensors)
+        if self._packed is None or sig != self._packed_sig:
+            dev = tensors[0].device
+            for n, t in zip(names, tensors):
+                if t.device != dev or t.dtype != torch.float32:
+                    raise native.EdttsError(f"weight {n}: expected fp32 on {dev}, got {t.dtype} on {t.device}")
+            dims = self.dims()
+            nbytes = native.packed_bytes(dims)
+            if self._packed is None or self._packed.numel() != nbytes or self._packed.device != dev:
+                self._packed = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            native.pack_weights(dims, [t.contiguous() for t in tensors], self._packed)
+            self._packed_sig = sig
+        return self._packed
+
+    def workspace(self, B: int, T: int, S: int, cond_rows: int, device) -> torch.Tensor:
+        key = (B, T, S, cond_rows, str(device))
+        ws = self._workspaces.get(key)
+        if ws is None:
+            if len(self._workspaces) >= 4:
+                self._workspaces.clear()
+            nbytes = native.workspace_bytes(self.dims(), B, T, S, cond_rows)
+            ws = torch.zeros(nbytes, dtype=torch.uint8, device=device)  # must start zero-filled (padding lanes)
+            self._workspaces[key] = ws
+        return ws
+
+    # ------------------------------------------------------------------------------------------ forward
+    @torch.no_grad()
+    def forward(self, x_t: torch.Tensor, t: torch.Tensor, sem_idx: Optional[torch.Tensor] = None,
+                step_idx: Optional[torch.Tensor] = None, sem_features: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """eps = decoder(x_t [B,T,n_mels], t [B], sem_idx [B,S] | sem_features [B,S,semantic_dim], step_idx [B] | None)."""
+        if sem_idx is None and sem_features is None:
+            raise ValueError("Either sem_idx or sem_features must be provided")
+        B, T, _ = x_t.shape
+        S = sem_features.shape[1] if sem_features is not None else sem_idx.shape[1]
+        packed = self._ensure_packed()
+        ws = self.workspace(B, T, S, B, x_t.device)
+        return native.decoder_forward(self.dims(), packed, ws, x_t.contiguous(), t.contiguous(),
+                                      None if step_idx is None else step_idx.contiguous(),
+                                      None if sem_features is not None or sem_idx is None else sem_idx.contiguous(),
+                                      None if sem_features is None else sem_features.contiguous(), S)

@@ -1,0 +1,186 @@
+"""ctypes binding of libedtts_hip.so (C ABI declared in include/edtts.h).
+
+This is the only door between the Python host classes and the HIP kernels.  There is NO fallback: if the
+shared library is missing, or a tensor is not a contiguous fp32/int64 tensor on a HIP device, the call raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get("EDTTS_LIB", os.path.join(os.path.dirname(_PKG_DIR), "lib", "libedtts_hip.so"))
+
+# every symbol include/edtts.h declares (tests check that the built library exports all of them)
+EXPORTED_SYMBOLS = (
+    "edtts_version", "edtts_last_error", "edtts_num_global_slots", "edtts_num_layer_slots", "edtts_global_slot_name",
+    "edtts_layer_slot_name", "edtts_packed_bytes", "edtts_pack_weights", "edtts_workspace_bytes", "edtts_decoder_forward",
+    "edtts_ddim_step", "edtts_ddpm_step", "edtts_generate", "edtts_dsconv_forward",
+)
+
+
+class EdttsDims(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "hidden", "layers", "heads", "n_mels", "ffn_mult", "codebook_size", "semantic_dim", "window", "max_pos",
+        "max_ctx_pos", "n_step_emb")]
+
+
+class EdttsError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load the HIP library (once).  Raises if it has not been built -- there is no CPU path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise EdttsError(
+            f"HIP extension not found at {LIB_PATH}; build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  The sampler path has no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp, i32, sz, f32 = C.c_void_p, C.c_int, C.c_size_t, C.c_float
+    L.edtts_version.restype = i32
+    L.edtts_last_error.restype = C.c_char_p
+    L.edtts_num_global_slots.restype = i32
+    L.edtts_num_layer_slots.restype = i32
+    L.edtts_global_slot_name.restype = C.c_char_p
+    L.edtts_global_slot_name.argtypes = [i32]
+    L.edtts_layer_slot_name.restype = C.c_char_p
+    L.edtts_layer_slot_name.argtypes = [i32]
+    L.edtts_packed_bytes.argtypes = [C.POINTER(EdttsDims), C.POINTER(sz)]
+    L.edtts_pack_weights.argtypes = [C.POINTER(EdttsDims), C.POINTER(vp), i32, vp, vp]
+    L.edtts_workspace_bytes.argtypes = [C.POINTER(EdttsDims), i32, i32, i32, i32, C.POINTER(sz)]
+    L.edtts_decoder_forward.argtypes = [C.POINTER(EdttsDims), vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp]
+    L.edtts_ddim_step.argtypes = [vp, i32, vp, vp, vp, vp, i32, sz, f32, vp, vp, vp, vp]
+    L.edtts_ddpm_step.argtypes = [vp, vp, vp, vp, i32, vp, vp, vp, i32, sz, vp, vp, vp]
+    L.edtts_generate.argtypes = [C.POINTER(EdttsDims), vp, vp, i32, i32, vp, vp, i32, C.POINTER(C.c_int64),
+                                 C.POINTER(f32), vp, vp, vp]
+    L.edtts_dsconv_forward.argtypes = [vp] * 6 + [i32] * 6 + [vp, vp, vp]
+    for name in EXPORTED_SYMBOLS:
+        fn = getattr(L, name)
+        if fn.restype is C.c_int and name not in ("edtts_version", "edtts_num_global_slots", "edtts_num_layer_slots"):
+            fn.errcheck = _errcheck
+    _lib = L
+    return L
+
+
+def _errcheck(rc, func, args):
+    if rc != 0:
+        msg = _lib.edtts_last_error().decode() if _lib is not None else "?"
+        # -2 = argument errors: the reference raises ValueError / IndexError / RuntimeError for these
+        if rc == -2 and "Either sem_idx or sem_features" in msg:
+            raise ValueError(msg)
+        raise EdttsError(f"{func.__name__} failed (code {rc}): {msg}")
+    return rc
+
+
+# ---------------------------------------------------------------------------------------------- helpers
+def _dev_ptr(t: Optional[torch.Tensor], dtype: torch.dtype, name: str) -> Optional[int]:
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise EdttsError(f"{name}: expected a tensor on the HIP device, got {t.device} -- the MI355X sampler path has no CPU fallback")
+    if t.dtype != dtype:
+        raise EdttsError(f"{name}: expected dtype {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise EdttsError(f"{name}: tensor must be contiguous")
+    return t.data_ptr()
+
+
+def _stream(device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def slot_names(n_layers: int) -> List[str]:
+    L = lib()
+    names = [L.edtts_global_slot_name(i).decode() for i in range(L.edtts_num_global_slots())]
+    per = [L.edtts_layer_slot_name(i).decode() for i in range(L.edtts_num_layer_slots())]
+    for l in range(n_layers):
+        names += [f"layers.{l}.{n}" for n in per]
+    return names
+
+
+def packed_bytes(dims: EdttsDims) -> int:
+    out = C.c_size_t(0)
+    lib().edtts_packed_bytes(C.byref(dims), C.byref(out))
+    return out.value
+
+
+def workspace_bytes(dims: EdttsDims, B: int, T: int, S: int, cond_rows: int) -> int:
+    out = C.c_size_t(0)
+    lib().edtts_workspace_bytes(C.byref(dims), B, T, S, cond_rows, C.byref(out))
+    return out.value
+
+
+def pack_weights(dims: EdttsDims, tensors: Sequence[torch.Tensor], packed: torch.Tensor) -> None:
+    ptrs = (C.c_void_p * len(tensors))(*[_dev_ptr(t, torch.float32, f"weight[{i}]") for i, t in enumerate(tensors)])
+    lib().edtts_pack_weights(C.byref(dims), ptrs, len(tensors), _dev_ptr(packed, torch.uint8, "packed"), _stream(packed.device))
+
+
+def decoder_forward(dims: EdttsDims, packed: torch.Tensor, workspace: torch.Tensor, x: torch.Tensor, t: torch.Tensor,
+                    step_idx: Optional[torch.Tensor], sem_idx: Optional[torch.Tensor], sem_features: Optional[torch.Tensor],
+                    S: int) -> torch.Tensor:
+    B, T, M = x.shape
+    eps = torch.empty_like(x)
+    lib().edtts_decoder_forward(
+        C.byref(dims), packed.data_ptr(), workspace.data_ptr(), B, T, S, _dev_ptr(x, torch.float32, "x_t"),
+        _dev_ptr(t, torch.int64, "t"), _dev_ptr(step_idx, torch.int64, "step_idx"), _dev_ptr(sem_idx, torch.int64, "sem_idx"),
+        _dev_ptr(sem_features, torch.float32, "sem_features"), eps.data_ptr(), _stream(x.device))
+    return eps
+
+
+def generate(dims: EdttsDims, packed: torch.Tensor, workspace: torch.Tensor, sem_idx: torch.Tensor, x_T: torch.Tensor,
+             timesteps: Sequence[int], coefs: Sequence[Tuple[float, float, float, float]]) -> torch.Tensor:
+    B, S = sem_idx.shape
+    n = len(timesteps)
+    ts = (C.c_int64 * n)(*[int(v) for v in timesteps])
+    flat = [float(v) for c in coefs for v in c]
+    cf = (C.c_float * (4 * n))(*flat)
+    x_work = torch.empty_like(x_T)
+    x0 = torch.empty_like(x_T)
+    lib().edtts_generate(C.byref(dims), packed.data_ptr(), workspace.data_ptr(), B, S, _dev_ptr(sem_idx, torch.int64, "sem_idx"),
+                         _dev_ptr(x_T, torch.float32, "x_T"), n, ts, cf, x_work.data_ptr(), x0.data_ptr(), _stream(x_T.device))
+    return x0
+
+
+def ddim_step(alpha_bar: torch.Tensor, x_t: torch.Tensor, t: torch.Tensor, t_prev: torch.Tensor, eps: torch.Tensor, eta: float,
+              noise: Optional[torch.Tensor]) -> Tuple[torch.Tensor, torch.Tensor]:
+    if x_t.shape != eps.shape:
+        raise EdttsError(f"x_t {tuple(x_t.shape)} and eps_pred {tuple(eps.shape)} differ")
+    B = x_t.shape[0]
+    x_prev, x0 = torch.empty_like(x_t), torch.empty_like(x_t)
+    lib().edtts_ddim_step(_dev_ptr(alpha_bar, torch.float32, "alpha_bar"), alpha_bar.numel(), _dev_ptr(x_t, torch.float32, "x_t"),
+                          _dev_ptr(eps, torch.float32, "eps_pred"), _dev_ptr(t, torch.int64, "t"), _dev_ptr(t_prev, torch.int64, "t_prev"),
+                          B, x_t.numel() // B, float(eta), _dev_ptr(noise, torch.float32, "noise"), x_prev.data_ptr(), x0.data_ptr(),
+                          _stream(x_t.device))
+    return x_prev, x0
+
+
+def ddpm_step(alphas, alpha_bar, betas, post_var, x_t, t, eps, noise) -> torch.Tensor:
+    B = x_t.shape[0]
+    out = torch.empty_like(x_t)
+    lib().edtts_ddpm_step(_dev_ptr(alphas, torch.float32, "alphas"), _dev_ptr(alpha_bar, torch.float32, "alpha_bar"),
+                          _dev_ptr(betas, torch.float32, "betas"), _dev_ptr(post_var, torch.float32, "posterior_variance"),
+                          alpha_bar.numel(), _dev_ptr(x_t, torch.float32, "x_t"), _dev_ptr(eps, torch.float32, "eps_pred"),
+                          _dev_ptr(t, torch.int64, "t"), B, x_t.numel() // B, _dev_ptr(noise, torch.float32, "noise"), out.data_ptr(),
+                          _stream(x_t.device))
+    return out
+
+
+def dsconv_forward(x, dw, pw, pb, gn_w, gn_b, groups: int) -> torch.Tensor:
+    B, Ci, T = x.shape
+    Co, ks = pw.shape[0], dw.shape[-1]
+    y = torch.empty(B, Co, T, device=x.device, dtype=torch.float32)
+    scratch = torch.empty(B * Co * T + 2 * B * groups, device=x.device, dtype=torch.float32)
+    f = torch.float32
+    lib().edtts_dsconv_forward(_dev_ptr(x, f, "x"), _dev_ptr(dw, f, "depthwise.weight"), _dev_ptr(pw, f, "pointwise.weight"),
+                               _dev_ptr(pb, f, "pointwise.bias"), _dev_ptr(gn_w, f, "norm.weight"), _dev_ptr(gn_b, f, "norm.bias"),
+                               B, Ci, Co, T, ks, groups, scratch.data_ptr(), y.data_ptr(), _stream(x.device))
+    return y

@@ -1,0 +1,122 @@
+"""DiffusionSchedule -- cosine noise schedule tables + the DDIM / DDPM updates, MI355X path.
+
+API mirror of /root/reference/edge_diffusion_tts/schedule.py:11-266.  The nine public tables are built on
+the CPU in fp32 with the same operation sequence as the reference (schedule.py:36-59) so they are bit-equal
+to the oracle's, then moved with ``.to(device)``.  ``get_ddim_step`` (schedule.py:157-202) and ``ddpm_step``
+(schedule.py:204-238) run as hand-written HIP kernels through the C ABI (include/edtts.h: edtts_ddim_step,
+edtts_ddpm_step); there is no CPU fallback for them -- CPU tensors raise.
+The light-weight algebra helpers (q_sample, predict_*, get_v_target) are not part of the sampler hot loop
+and stay ordinary torch expressions.
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Optional, Tuple
+
+import torch
+
+_TABLES = (
+    "betas", "alphas", "alpha_bar", "sqrt_alpha_bar", "sqrt_one_minus_alpha_bar", "sqrt_recip_alpha_bar",
+    "sqrt_recip_alpha_bar_minus_one", "posterior_variance", "lambda_t",
+)
+
+
+def _bcast(tab: torch.Tensor, t: torch.Tensor) -> torch.Tensor:
+    return tab[t].reshape(-1, 1, 1)
+
+
+class DiffusionSchedule:
+    TABLE_NAMES = _TABLES
+
+    def __init__(self, T: int, beta_start: float = 1e-4, beta_end: float = 2e-2, device: str = "cpu"):
+        # beta_start / beta_end are accepted and ignored, as in the reference (cosine schedule, s = 0.008).
+        self.T = int(T)
+        self.device = device
+        s = 0.008
+        grid = torch.linspace(0, T, T + 1, dtype=torch.float32)
+        ac = torch.cos(((grid / T) + s) / (1 + s) * torch.pi * 0.5) ** 2
+        ac = ac / ac[0]
+        self.betas = torch.clip(1 - (ac[1:] / ac[:-1]), 0.0001, 0.9999)
+        self.alphas = 1.0 - self.betas
+        self.alpha_bar = torch.cumprod(self.alphas, dim=0)
+        self.sqrt_alpha_bar = torch.sqrt(self.alpha_bar)
+        self.sqrt_one_minus_alpha_bar = torch.sqrt(1.0 - self.alpha_bar)
+        self.sqrt_recip_alpha_bar = torch.sqrt(1.0 / self.alpha_bar)
+        self.sqrt_recip_alpha_bar_minus_one = torch.sqrt(1.0 / self.alpha_bar - 1)
+        ab_prev = torch.cat([torch.ones(1, dtype=torch.float32), self.alpha_bar[:-1]])
+        self.posterior_variance = self.betas * (1.0 - ab_prev) / (1.0 - self.alpha_bar)
+        self.lambda_t = torch.log(self.sqrt_alpha_bar / self.sqrt_one_minus_alpha_bar)
+        if str(device) != "cpu":
+            self.to(device)
+
+    # ------------------------------------------------------------------ tables / movement
+    def to(self, device) -> "DiffusionSchedule":
+        self.device = device
+        for name in _TABLES:
+            setattr(self, name, getattr(self, name).to(device))
+        return self
+
+    def get_schedule_for_steps(self, num_steps: int) -> List[int]:
+        stride = self.T // num_steps
+        return list(range(self.T - 1, 0, -stride))[:num_steps]
+
+    # ------------------------------------------------------------------ light algebra (not hot path)
+    def q_sample(self, x0, t, noise=None):
+        if noise is None:
+            noise = torch.randn_like(x0)
+        return _bcast(self.sqrt_alpha_bar, t) * x0 + _bcast(self.sqrt_one_minus_alpha_bar, t) * noise, noise
+
+    def predict_x0_from_eps(self, x_t, t, eps):
+        return _bcast(self.sqrt_recip_alpha_bar, t) * x_t - _bcast(self.sqrt_recip_alpha_bar_minus_one, t) * eps
+
+    def predict_x0_from_v(self, x_t, t, v):
+        return _bcast(self.sqrt_alpha_bar, t) * x_t - _bcast(self.sqrt_one_minus_alpha_bar, t) * v
+
+    def predict_eps_from_v(self, x_t, t, v):
+        return _bcast(self.sqrt_one_minus_alpha_bar, t) * x_t + _bcast(self.sqrt_alpha_bar, t) * v
+
+    def get_v_target(self, x0, noise, t):
+        return _bcast(self.sqrt_alpha_bar, t) * noise - _bcast(self.sqrt_one_minus_alpha_bar, t) * x0
+
+    # ------------------------------------------------------------------ hot path: HIP kernels
+    def get_ddim_step(self, x_t: torch.Tensor, t: torch.Tensor, t_prev: torch.Tensor, eps_pred: torch.Tensor,
+                      eta: float = 0.0, noise: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+        """One DDIM update (x0-prediction, clamp to [-3, 3], deterministic for eta == 0).
+
+        Returns ``(x_prev, x0_pred)`` as fresh tensors.  ``noise`` (only used when eta > 0) is a superset of
+        the reference signature: when omitted it is drawn with ``torch.randn_like`` like the reference does.
+        """
+        from . import native
+        if eta > 0 and noise is None:
+            noise = torch.randn_like(x_t)
+        return native.ddim_step(self.alpha_bar, x_t, t, t_prev, eps_pred, float(eta), noise if eta > 0 else None)
+
+    def ddpm_step(self, x_t: torch.Tensor, t: torch.Tensor, eps_pred: torch.Tensor,
+                  noise: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """One ancestral DDPM update; noise defaults to ``torch.randn_like(x_t)`` (reference behaviour)."""
+        from . import native
+        if noise is None:
+            noise = torch.randn_like(x_t)
+        return native.ddpm_step(self.alphas, self.alpha_bar, self.betas, self.posterior_variance, x_t, t, eps_pred, noise)
+
+    # ------------------------------------------------------------------ host-side scalars for the fused loop
+    def ddim_coefficients(self, t: int, t_prev: int, eta: float = 0.0) -> Tuple[float, float, float, float]:
+        """fp32 scalars (sqrt(1-ab), sqrt(ab), sqrt(ab_prev), sqrt(1-ab_prev-sigma^2)) for one batch-uniform DDIM step
+        (inference.py:39-42), following the reference's per-element expression sequence (schedule.py:179-196) with
+        every operation correctly rounded to fp32: +,-,*,/ on numpy float32 scalars, sqrt through fp64 (exact for
+        fp32).  This is what the reference's CPU path produces on a host whose vector sqrt is correctly rounded, and
+        it is bit-identical to the in-kernel evaluation of edtts_ddim_step -- unlike torch.sqrt on some hosts."""
+        import numpy as np
+        f32 = np.float32
+
+        def sqrt32(v):
+            return f32(np.sqrt(np.float64(v)))
+
+        tab = self.alpha_bar.detach().to("cpu")
+        ab = f32(tab[t].item())
+        ab_prev = f32(tab[t_prev].item()) if t_prev >= 0 else f32(1.0)
+        one = f32(1.0)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            sigma = f32(eta) * sqrt32(((one - ab_prev) / (one - ab)) * (one - ab / ab_prev))
+        return (float(sqrt32(one - ab)), float(sqrt32(ab)), float(sqrt32(ab_prev)),
+                float(sqrt32((one - ab_prev) - sigma * sigma)))

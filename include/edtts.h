@@ -1,0 +1,130 @@
+/*
+ * edtts.h -- C ABI of libedtts_hip.so: the MI355X (gfx950) implementation of the DDIM few-step sampler path
+ * of Krabbens/edge-diffusion-tts.
+ *
+ * The reference has no FFI of its own (pure Python/PyTorch); the interface this library
+ * sits behind is the reference's Python class API.  Each entry point below names the reference code whose
+ * arithmetic it replaces (paths relative to /root/reference/edge_diffusion_tts/).  The Python host package
+ * (edge-diffusion-tts_amd/edge_diffusion_tts_amd/native.py) binds these symbols with ctypes; INTEGRATION.md
+ * shows the binding a reference maintainer would add.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every data pointer is a DEVICE pointer unless the comment says "host".
+ *   - all tensors are dense fp32, channel-last [B, T, n_mels] / [B, T, hidden]; indices are int64.
+ *   - the caller owns every buffer (inputs, outputs, packed weights, workspace); the library never
+ *     allocates device memory, never synchronises the host, and only enqueues work on `stream`
+ *     (a hipStream_t passed as void*; NULL = the null stream).  All calls are graph-capturable.
+ *   - return value: 0 on success, a negative EDTTS_ERR_* otherwise; edtts_last_error() returns a
+ *     thread-local message for the last failing call.
+ */
+#ifndef EDTTS_H_
+#define EDTTS_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EDTTS_VERSION 100 /* 0.1.0 */
+
+enum {
+  EDTTS_OK = 0,
+  EDTTS_ERR_UNSUPPORTED = -1, /* dims have no compiled kernel instance            */
+  EDTTS_ERR_ARG = -2,         /* null pointer / size out of range (IndexError/RuntimeError analogue) */
+  EDTTS_ERR_HIP = -3          /* a HIP runtime call or launch failed              */
+};
+
+/* Decoder hyper-parameters: the CFG fields read by models/decoder.py:17-64 plus table sizes. */
+typedef struct EdttsDims {
+  int32_t hidden;        /* CFG.hidden            (config.py:103) */
+  int32_t layers;        /* CFG.layers                            */
+  int32_t heads;         /* CFG.heads                             */
+  int32_t n_mels;        /* CFG.n_mels                            */
+  int32_t ffn_mult;      /* CFG.ffn_mult (only 2 is compiled)     */
+  int32_t codebook_size; /* CFG.codebook_size: rows of token_emb  */
+  int32_t semantic_dim;  /* CFG.semantic_dim: sem_proj input      */
+  int32_t window;        /* CFG.attn_window_size; < 0 = full self-attention (window_size=None) */
+  int32_t max_pos;       /* rows of pos_emb.pe         (decoder.py:38: 1000) */
+  int32_t max_ctx_pos;   /* rows of context_pos_emb.pe (decoder.py:41: 512)  */
+  int32_t n_step_emb;    /* rows of step_emb           (decoder.py:32: 16)   */
+} EdttsDims;
+
+int edtts_version(void);
+const char* edtts_last_error(void);
+
+/* ---- weights ------------------------------------------------------------------------------------------
+ * The decoder state-dict (key names = SURVEY.md section 8a row 5 = decoder.state_dict() of
+ * models/decoder.py:17-64) is handed over as an array of device pointers, one per "slot".  Slots
+ * [0, n_global) are the non-layer tensors, then n_layer slots per transformer layer.  The slot -> key-name
+ * mapping is queried, so the host never hard-codes the order.  Name "time_freqs" is the one derived slot:
+ * the fp32 frequency row of SinusoidalTimeEmb (layers/embeddings.py:38-41), computed by the host exactly as
+ * the reference does. */
+int edtts_num_global_slots(void);
+int edtts_num_layer_slots(void);
+const char* edtts_global_slot_name(int i); /* e.g. "token_emb.weight" */
+const char* edtts_layer_slot_name(int i);  /* e.g. "attn.qkv.weight" (prefix "layers.<l>." added by the host) */
+
+/* Size of the packed-weight blob (MFMA-fragment order GEMM operands + tables) for these dims. */
+int edtts_packed_bytes(const EdttsDims* dims, size_t* out_bytes);
+/* Re-pack the state-dict into `packed` (once per weight load). slots: host array of device pointers. */
+int edtts_pack_weights(const EdttsDims* dims, const void* const* slots, int n_slots, void* packed, void* stream);
+
+/* ---- workspace ----------------------------------------------------------------------------------------
+ * Scratch for activations (h, q, k, v^T), the per-call cross-attention K/V cache and the AdaLN rows.
+ * cond_rows = number of (t, step_idx) rows the conditioning kernel is run for (B for a plain forward,
+ * num_steps for the fused sampler).  The workspace must be ZERO-FILLED once after allocation (padding
+ * lanes are read but never written) and may then be reused for any number of calls of the same shape. */
+int edtts_workspace_bytes(const EdttsDims* dims, int B, int T, int S, int cond_rows, size_t* out_bytes);
+
+/* ---- decoder forward  (models/decoder.py:66-109, EdgeDiffusionDecoder.forward) --------------------------
+ * x [B,T,n_mels], t [B] int64, step_idx [B] int64 or NULL, exactly one of sem_idx [B,S] int64 /
+ * sem_features [B,S,semantic_dim] non-NULL (both NULL -> EDTTS_ERR_ARG, the reference's ValueError,
+ * decoder.py:90).  Writes eps [B,T,n_mels].  T <= max_pos, S <= max_ctx_pos, step_idx < n_step_emb are the
+ * reference's limits; the first two are checked here, index contents are the caller's. */
+int edtts_decoder_forward(const EdttsDims* dims, const void* packed, void* workspace, int B, int T, int S,
+                          const float* x, const int64_t* t, const int64_t* step_idx, const int64_t* sem_idx,
+                          const float* sem_features, float* eps, void* stream);
+
+/* ---- DDIM update  (schedule.py:157-202, DiffusionSchedule.get_ddim_step) --------------------------------
+ * alpha_bar [n_table] fp32 table; t, t_prev [B] int64 (t_prev < 0 -> alpha_bar_prev = 1); n_per_batch =
+ * T*n_mels; eta >= 0; noise [B,T,n_mels] or NULL (required when eta > 0).  Writes x_prev and x0 (clamped
+ * to [-3,3]).  Same operation order as the reference: division by sqrt(ab), direction from the raw eps. */
+int edtts_ddim_step(const float* alpha_bar, int n_table, const float* x, const float* eps, const int64_t* t,
+                    const int64_t* t_prev, int B, size_t n_per_batch, float eta, const float* noise,
+                    float* x_prev, float* x0, void* stream);
+
+/* ---- DDPM update  (schedule.py:204-238, DiffusionSchedule.ddpm_step) ------------------------------------
+ * tables: alphas, alpha_bar, betas, posterior_variance [n_table]; noise [B,T,n_mels] is the draw the
+ * reference takes from torch.randn_like (the host supplies it). */
+int edtts_ddpm_step(const float* alphas, const float* alpha_bar, const float* betas, const float* post_var,
+                    int n_table, const float* x, const float* eps, const int64_t* t, int B, size_t n_per_batch,
+                    const float* noise, float* x_prev, void* stream);
+
+/* ---- whole sampler loop  (inference.py:23-53, EdgeInference.generate_mel) -------------------------------
+ * sem_idx [B,S] int64; x_T [B,2S,n_mels] initial noise (already multiplied by temperature);
+ * num_steps in [1, n_step_emb]; timesteps (host) int64[num_steps] as produced by
+ * range(diff_steps-1, 0, -stride)[:num_steps]; coef (host) float[num_steps*4] =
+ * {sqrt(1-ab_t), sqrt(ab_t), sqrt(ab_prev), sqrt(1-ab_prev)} per step (eta = 0), computed in fp32 by the
+ * host with the reference's own expressions.  x_work [B,2S,n_mels] is scratch for x_t; x0_out receives the
+ * last step's clamped x0 prediction (what generate_mel returns, inference.py:53).
+ * The cross-attention K/V and all AdaLN rows are computed once per call; each step's final transformer
+ * layer fuses final_norm + out_proj + the DDIM update. */
+int edtts_generate(const EdttsDims* dims, const void* packed, void* workspace, int B, int S,
+                   const int64_t* sem_idx, const float* x_T, int num_steps, const int64_t* timesteps_host,
+                   const float* coef_host, float* x_work, float* x0_out, void* stream);
+
+/* ---- depthwise-separable Conv1d  (layers/conv.py:25-64, DepthwiseSeparableConv.forward) -----------------
+ * Standalone exported layer (named by the north star; the decoder never calls it).
+ * x [B,C_in,T] channel-first; dw [C_in,k] depthwise taps (stride 1, zero pad k/2, no bias); pw [C_out,C_in],
+ * pb [C_out]; GroupNorm(groups, eps 1e-5, affine gn_w/gn_b [C_out]) then exact (erf) GELU -> y [B,C_out,T].
+ * scratch: at least B*C_out*T + 2*B*groups floats. */
+int edtts_dsconv_forward(const float* x, const float* dw, const float* pw, const float* pb, const float* gn_w,
+                         const float* gn_b, int B, int C_in, int C_out, int T, int ksize, int groups,
+                         float* scratch, float* y, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EDTTS_H_ */

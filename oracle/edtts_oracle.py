@@ -1,0 +1,291 @@
+"""CPU ORACLE for the DDIM sampler path -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+A functional (no nn.Module) restatement, in plain PyTorch CPU tensor algebra, of the reference algorithm
+    EdgeInference.generate_mel          /root/reference/edge_diffusion_tts/inference.py:23-53
+    EdgeDiffusionDecoder.forward        /root/reference/edge_diffusion_tts/models/decoder.py:66-109
+    DiffusionSchedule (+get_ddim_step)  /root/reference/edge_diffusion_tts/schedule.py:26-59,157-238
+    DepthwiseSeparableConv.forward      /root/reference/edge_diffusion_tts/layers/conv.py:52-64
+written from the math in SURVEY.md section 8a; every function cites the reference lines it follows.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module; the product
+package (edge-diffusion-tts_amd/) never does and fails loudly without its HIP library.
+
+Pinning: PINNED.  The reference has no tests or golden vectors of its own, so this
+oracle is pinned against outputs of the reference itself, run on CPU in the build container by
+tests/golden/make_golden.py (committed, with the fixtures it produced under tests/golden/*.npz) and checked
+by tests/test_oracle_vs_golden.py.
+
+All functions take a flat ``sd`` mapping (the reference state-dict key names)
+and work in the dtype of the tensors they are given: fp32 is the parity oracle, fp64 (``cast_sd(sd,
+torch.float64)``) is the arbiter used for the t=999 amplification band.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+Tensor = torch.Tensor
+SD = Dict[str, Tensor]
+
+
+# ------------------------------------------------------------------------------------------------
+# small pieces
+# ------------------------------------------------------------------------------------------------
+def cast_sd(sd: SD, dtype: torch.dtype) -> SD:
+    return {k: (v.to(dtype) if v.is_floating_point() else v) for k, v in sd.items()}
+
+
+def linear(x: Tensor, w: Tensor, b: Optional[Tensor] = None) -> Tensor:
+    y = x @ w.transpose(-1, -2)
+    return y if b is None else y + b
+
+
+def rms_norm(x: Tensor, weight: Tensor, eps: float = 1e-6) -> Tensor:
+    """layers/mla.py:46-58 -- x * rsqrt(mean(x^2) + eps) * weight."""
+    return x * torch.rsqrt(x.pow(2).mean(dim=-1, keepdim=True) + eps) * weight
+
+
+def ada_rms_norm(x: Tensor, cond: Tensor, sd: SD, prefix: str) -> Tensor:
+    """layers/transformer.py:64-68 -- scale is the FIRST half of proj(cond), shift the second."""
+    mod = linear(cond, sd[prefix + "proj.weight"], sd[prefix + "proj.bias"])
+    H = x.shape[-1]
+    scale, shift = mod[:, :H], mod[:, H:]
+    return rms_norm(x, sd[prefix + "norm.weight"]) * (1 + scale[:, None, :]) + shift[:, None, :]
+
+
+def gelu_erf(x: Tensor) -> Tensor:
+    return 0.5 * x * (1.0 + torch.erf(x / math.sqrt(2.0)))
+
+
+def time_frequencies(H: int) -> Tensor:
+    """layers/embeddings.py:38-41 -- always fp32, divisor (half - 1)."""
+    half = H // 2
+    return torch.exp(torch.arange(half, dtype=torch.float32) * (-math.log(10000.0) / (half - 1)))
+
+
+def sinusoidal_time_emb(t: Tensor, H: int, dtype: torch.dtype) -> Tensor:
+    """layers/embeddings.py:27-43 -- cat[sin, cos] of t.float() * freqs (fp32 hard-coded in the reference;
+    the fp64 arbiter evaluates the trig in fp64 on the same fp32 frequencies)."""
+    freqs = time_frequencies(H)
+    if dtype == torch.float64:
+        args = t.to(torch.float64)[:, None] * freqs.to(torch.float64)[None, :]
+    else:
+        args = t.float()[:, None] * freqs[None, :]
+    return torch.cat([torch.sin(args), torch.cos(args)], dim=1).to(dtype)
+
+
+def positional_table(max_len: int, H: int) -> Tensor:
+    """layers/embeddings.py:119-140 -- interleaved sin/cos table, fp32."""
+    pe = torch.zeros(max_len, H)
+    pos = torch.arange(0, max_len).unsqueeze(1)
+    div = torch.exp(torch.arange(0, H, 2) * (-math.log(10000.0) / H))
+    pe[:, 0::2] = torch.sin(pos * div)
+    pe[:, 1::2] = torch.cos(pos * div)
+    return pe
+
+
+def band_mask(T: int, window: int) -> Tensor:
+    """layers/attention.py:27-30 -- True where |i - j| <= window."""
+    idx = torch.arange(T)
+    return (idx[None, :] - idx[:, None]).abs() <= window
+
+
+def attention(q: Tensor, k: Tensor, v: Tensor, mask: Optional[Tensor]) -> Tensor:
+    """softmax(q k^T / sqrt(d) [masked]) v on [B, h, T, d] tensors (what F.scaled_dot_product_attention
+    computes for layers/attention.py:108-112 and layers/mla.py:175-179, dropout off)."""
+    s = (q @ k.transpose(-1, -2)) * (q.shape[-1] ** -0.5)
+    if mask is not None:
+        s = s.masked_fill(~mask, float("-inf"))
+    return torch.softmax(s, dim=-1) @ v
+
+
+def split_heads(x: Tensor, heads: int) -> Tensor:
+    B, T, H = x.shape
+    return x.reshape(B, T, heads, H // heads).transpose(1, 2)
+
+
+def merge_heads(x: Tensor) -> Tensor:
+    B, h, T, d = x.shape
+    return x.transpose(1, 2).reshape(B, T, h * d)
+
+
+# ------------------------------------------------------------------------------------------------
+# decoder pieces (each usable alone for per-op parity tests)
+# ------------------------------------------------------------------------------------------------
+def time_condition(sd: SD, t: Tensor, step_idx: Optional[Tensor]) -> Tensor:
+    """models/decoder.py:26-32,77-80 -- Linear(GELU(Linear(sinus(t)))) + step_emb[step_idx]."""
+    w1 = sd["time_emb.1.weight"]
+    H = w1.shape[0]
+    e = sinusoidal_time_emb(t, H, w1.dtype)
+    c = linear(gelu_erf(linear(e, w1, sd["time_emb.1.bias"])), sd["time_emb.3.weight"], sd["time_emb.3.bias"])
+    if step_idx is not None:
+        c = c + sd["step_emb.weight"][step_idx]
+    return c
+
+
+def context_embed(sd: SD, sem_idx: Optional[Tensor], sem_features: Optional[Tensor]) -> Tensor:
+    """models/decoder.py:83-93 -- token_emb gather (or sem_proj of features) + context positional table."""
+    if sem_features is not None:
+        ctx = linear(sem_features, sd["sem_proj.weight"], sd["sem_proj.bias"])
+    elif sem_idx is not None:
+        ctx = sd["token_emb.weight"][sem_idx]
+    else:
+        raise ValueError("Either sem_idx or sem_features must be provided")
+    return ctx + sd["context_pos_emb.pe"][: ctx.shape[1]]
+
+
+def input_embed(sd: SD, x_t: Tensor) -> Tensor:
+    """models/decoder.py:96-97 -- in_proj + positional table."""
+    return linear(x_t, sd["in_proj.weight"], sd["in_proj.bias"]) + sd["pos_emb.pe"][: x_t.shape[1]]
+
+
+def self_attention(sd: SD, p: str, x: Tensor, heads: int, window: Optional[int]) -> Tensor:
+    """layers/attention.py:77-123 -- qkv rows ordered q|k|v, each head-major; band mask; proj with bias."""
+    H = x.shape[-1]
+    qkv = linear(x, sd[p + "qkv.weight"])
+    q, k, v = (split_heads(qkv[..., i * H:(i + 1) * H], heads) for i in range(3))
+    mask = band_mask(x.shape[1], window) if window is not None else None
+    return linear(merge_heads(attention(q, k, v, mask)), sd[p + "proj.weight"], sd[p + "proj.bias"])
+
+
+def cross_kv(sd: SD, p: str, ctx: Tensor, heads: int) -> Tuple[Tensor, Tensor]:
+    """layers/mla.py:143-153 -- kv_down -> RMSNorm(rank) -> kv_up; K = first H columns, V = second."""
+    c = rms_norm(linear(ctx, sd[p + "kv_down_proj.weight"]), sd[p + "kv_norm.weight"])
+    kv = linear(c, sd[p + "kv_up_proj.weight"])
+    H = kv.shape[-1] // 2
+    return split_heads(kv[..., :H], heads), split_heads(kv[..., H:], heads)
+
+
+def cross_attention(sd: SD, p: str, x: Tensor, ctx: Tensor, heads: int) -> Tensor:
+    """layers/mla.py:118-194 in cross mode -- no RoPE (:158-160), no mask (:164), no biases."""
+    q = split_heads(linear(x, sd[p + "q_proj.weight"]), heads)
+    k, v = cross_kv(sd, p, ctx, heads)
+    return linear(merge_heads(attention(q, k, v, None)), sd[p + "out_proj.weight"])
+
+
+def feed_forward(sd: SD, p: str, x: Tensor) -> Tensor:
+    """layers/transformer.py:13-49 -- up-projection, value = first half, gate = second half, value*silu(gate)."""
+    u = linear(x, sd[p + "net.0.weight"], sd[p + "net.0.bias"])
+    half = u.shape[-1] // 2
+    a, g = u[..., :half], u[..., half:]
+    return linear(a * (g * torch.sigmoid(g)), sd[p + "net.3.weight"], sd[p + "net.3.bias"])
+
+
+def transformer_block(sd: SD, p: str, h: Tensor, ctx: Tensor, cond: Tensor, heads: int, window: Optional[int]) -> Tensor:
+    """layers/transformer.py:129-160 -- three pre-norm residual branches."""
+    h = h + self_attention(sd, p + "attn.", ada_rms_norm(h, cond, sd, p + "norm1."), heads, window)
+    h = h + cross_attention(sd, p + "cross_attn.", rms_norm(h, sd[p + "norm2.weight"]), ctx, heads)
+    h = h + feed_forward(sd, p + "ffn.", ada_rms_norm(h, cond, sd, p + "norm3."))
+    return h
+
+
+def layer_norm(x: Tensor, w: Tensor, b: Tensor, eps: float = 1e-5) -> Tensor:
+    mu = x.mean(dim=-1, keepdim=True)
+    var = (x - mu).pow(2).mean(dim=-1, keepdim=True)
+    return (x - mu) * torch.rsqrt(var + eps) * w + b
+
+
+def n_layers(sd: SD) -> int:
+    return 1 + max(int(k.split(".")[1]) for k in sd if k.startswith("layers."))
+
+
+def decoder_forward(sd: SD, x_t: Tensor, t: Tensor, sem_idx: Optional[Tensor] = None, step_idx: Optional[Tensor] = None,
+                    sem_features: Optional[Tensor] = None, *, heads: int = 4, window: Optional[int] = 64) -> Tensor:
+    """models/decoder.py:66-109."""
+    cond = time_condition(sd, t, step_idx)
+    ctx = context_embed(sd, sem_idx, sem_features)
+    h = input_embed(sd, x_t)
+    for i in range(n_layers(sd)):
+        h = transformer_block(sd, f"layers.{i}.", h, ctx, cond, heads, window)
+    return linear(layer_norm(h, sd["final_norm.weight"], sd["final_norm.bias"]), sd["out_proj.weight"], sd["out_proj.bias"])
+
+
+# ------------------------------------------------------------------------------------------------
+# schedule
+# ------------------------------------------------------------------------------------------------
+def schedule_tables(T: int = 1000, dtype: torch.dtype = torch.float32) -> Dict[str, Tensor]:
+    """schedule.py:36-59 -- cosine schedule (s = 0.008), betas clipped to [1e-4, 0.9999]; beta_start/end unused."""
+    s = 0.008
+    g = torch.linspace(0, T, T + 1, dtype=dtype)
+    ac = torch.cos(((g / T) + s) / (1 + s) * torch.pi * 0.5) ** 2
+    ac = ac / ac[0]
+    betas = torch.clip(1 - (ac[1:] / ac[:-1]), 0.0001, 0.9999)
+    alphas = 1.0 - betas
+    ab = torch.cumprod(alphas, dim=0)
+    ab_prev = torch.cat([torch.ones(1, dtype=dtype), ab[:-1]])
+    sab, s1m = torch.sqrt(ab), torch.sqrt(1.0 - ab)
+    return {
+        "betas": betas, "alphas": alphas, "alpha_bar": ab, "sqrt_alpha_bar": sab, "sqrt_one_minus_alpha_bar": s1m,
+        "sqrt_recip_alpha_bar": torch.sqrt(1.0 / ab), "sqrt_recip_alpha_bar_minus_one": torch.sqrt(1.0 / ab - 1),
+        "posterior_variance": betas * (1.0 - ab_prev) / (1.0 - ab), "lambda_t": torch.log(sab / s1m),
+    }
+
+
+def ddim_step(alpha_bar: Tensor, x_t: Tensor, t: Tensor, t_prev: Tensor, eps: Tensor, eta: float = 0.0,
+              noise: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
+    """schedule.py:157-202 -- division by sqrt(ab); clamp to [-3, 3]; direction uses the RAW eps."""
+    ab = alpha_bar[t][:, None, None]
+    ab_prev = torch.where((t_prev >= 0)[:, None, None], alpha_bar[t_prev.clamp(min=0)][:, None, None], torch.ones_like(ab))
+    x0 = torch.clamp((x_t - torch.sqrt(1 - ab) * eps) / torch.sqrt(ab), -3, 3)
+    sigma = eta * torch.sqrt((1 - ab_prev) / (1 - ab) * (1 - ab / ab_prev))
+    direction = torch.sqrt(1 - ab_prev - sigma ** 2) * eps
+    x_prev = torch.sqrt(ab_prev) * x0 + direction
+    if eta > 0:
+        x_prev = x_prev + sigma * noise
+    return x_prev, x0
+
+
+def ddpm_step(tabs: Dict[str, Tensor], x_t: Tensor, t: Tensor, eps: Tensor, noise: Tensor) -> Tensor:
+    """schedule.py:204-238 -- mean + [t>0] * sqrt(posterior_variance) * noise."""
+    a = tabs["alphas"][t][:, None, None]
+    ab = tabs["alpha_bar"][t][:, None, None]
+    b = tabs["betas"][t][:, None, None]
+    mean = (1.0 / torch.sqrt(a)) * (x_t - (b / torch.sqrt(1.0 - ab)) * eps)
+    nz = (t > 0).to(x_t.dtype)[:, None, None]
+    return mean + nz * torch.sqrt(tabs["posterior_variance"][t][:, None, None]) * noise
+
+
+def ddim_timesteps(diff_steps: int, num_steps: int) -> List[Tuple[int, int]]:
+    """inference.py:35-41 -- (t, t_prev) pairs."""
+    stride = diff_steps // num_steps
+    ts = list(range(diff_steps - 1, 0, -stride))[:num_steps]
+    return [(t, max(t - stride, 0)) for t in ts]
+
+
+def generate_mel(sd: SD, alpha_bar: Tensor, sem_idx: Tensor, x_T: Tensor, num_steps: int = 4, diff_steps: int = 1000,
+                 *, heads: int = 4, window: Optional[int] = 64, trace: Optional[list] = None) -> Tensor:
+    """inference.py:23-53 with the initial noise injected (the reference draws it from the global RNG, F10)."""
+    B = sem_idx.shape[0]
+    x = x_T
+    x0 = None
+    for i, (t, t_prev) in enumerate(ddim_timesteps(diff_steps, num_steps)):
+        tt = torch.full((B,), t, dtype=torch.long)
+        eps = decoder_forward(sd, x, tt, sem_idx, torch.full((B,), i, dtype=torch.long), heads=heads, window=window)
+        x, x0 = ddim_step(alpha_bar, x, tt, torch.full((B,), t_prev, dtype=torch.long), eps)
+        if trace is not None:
+            trace.append({"eps": eps, "x_prev": x, "x0": x0})
+    return x0
+
+
+# ------------------------------------------------------------------------------------------------
+# standalone exported layer named by north_star (not called by the decoder)
+# ------------------------------------------------------------------------------------------------
+def dsconv_forward(x: Tensor, dw: Tensor, pw: Tensor, pb: Tensor, gn_w: Tensor, gn_b: Tensor, groups: int, eps: float = 1e-5) -> Tensor:
+    """layers/conv.py:52-64 -- depthwise k-tap conv (zero pad k//2, no bias) -> pointwise 1x1 (+bias) ->
+    GroupNorm(groups) -> exact GELU.  x: [B, C_in, T]; dw: [C_in, 1, k]; pw: [C_out, C_in, 1]."""
+    B, C, T = x.shape
+    ksz = dw.shape[-1]
+    pad = ksz // 2
+    xp = torch.nn.functional.pad(x, (pad, pad))
+    y = torch.zeros_like(x)
+    for j in range(ksz):
+        y = y + xp[:, :, j:j + T] * dw[:, 0, j][None, :, None]
+    z = torch.einsum("oc,bct->bot", pw[:, :, 0], y) + pb[None, :, None]
+    Co = z.shape[1]
+    zg = z.reshape(B, groups, (Co // groups) * T)
+    mu = zg.mean(dim=-1, keepdim=True)
+    var = (zg - mu).pow(2).mean(dim=-1, keepdim=True)
+    zn = ((zg - mu) * torch.rsqrt(var + eps)).reshape(B, Co, T)
+    return gelu_erf(zn * gn_w[None, :, None] + gn_b[None, :, None])

@@ -1,0 +1,222 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE implementation on CPU (build container only).
+
+Usage (from the repo root; /root/reference must exist, it never travels to the GPU box):
+    python tests/golden/make_golden.py
+
+The script imports `edge_diffusion_tts` from /root/reference, loads it with this repo's deterministic synthetic
+weights (edge_diffusion_tts_amd.synth.synth_state_dict -- the reference zero-initialises out_proj / AdaLN, so its
+default init gives an identically-zero decoder) and records inputs + outputs of the sampler path.
+Only data (inputs and expected outputs) is written; no reference source is copied.
+"""
+import os
+import sys
+import tempfile
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+OUT = os.path.join(REPO, "tests", "golden")
+sys.dont_write_bytecode = True
+sys.path.insert(0, os.path.join(REPO, "edge-diffusion-tts_amd"))
+sys.path.insert(0, "/root/reference")
+
+# CFG() creates ./data and ./run_edge_diffusion in the cwd -> work in a scratch directory
+os.chdir(tempfile.mkdtemp(prefix="edtts_golden_"))
+torch.set_num_threads(8)
+
+import edge_diffusion_tts as ref  # noqa: E402  (the reference)
+from edge_diffusion_tts.layers.conv import DepthwiseSeparableConv as RefDSConv  # noqa: E402
+from edge_diffusion_tts.layers.embeddings import SinusoidalPositionalEmb as RefPosEmb  # noqa: E402
+from edge_diffusion_tts_amd.synth import synth_state_dict, hash_uniform  # noqa: E402
+
+
+def npf(t):
+    return t.detach().cpu().numpy()
+
+
+def rnd(shape, seed, stream, scale=1.0):
+    return torch.from_numpy((hash_uniform(shape, seed, stream) * scale).astype(np.float32))
+
+
+def rnd_idx(shape, hi, seed, stream):
+    u = (hash_uniform(shape, seed, stream) + 1.0) * 0.5
+    return torch.from_numpy(np.minimum((u * hi).astype(np.int64), hi - 1))
+
+
+def make_decoder(cfg, seed, max_pos=1000, max_ctx=512):
+    dec = ref.EdgeDiffusionDecoder(cfg).eval()
+    if max_pos != 1000:
+        dec.pos_emb = RefPosEmb(cfg.hidden, max_len=max_pos)  # the reference's own class, longer table
+    if max_ctx != 512:
+        dec.context_pos_emb = RefPosEmb(cfg.hidden, max_len=max_ctx)
+    missing = dec.load_state_dict(synth_state_dict(cfg, seed, max_pos, max_ctx), strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    return dec
+
+
+@torch.no_grad()
+def main():
+    saved = {}
+
+    # ---- 1. schedule tables (schedule.py:26-59) -------------------------------------------------------
+    sch = ref.DiffusionSchedule(1000)
+    names = ["betas", "alphas", "alpha_bar", "sqrt_alpha_bar", "sqrt_one_minus_alpha_bar", "sqrt_recip_alpha_bar",
+             "sqrt_recip_alpha_bar_minus_one", "posterior_variance", "lambda_t"]
+    np.savez_compressed(os.path.join(OUT, "schedule_tables.npz"), **{n: npf(getattr(sch, n)) for n in names})
+    saved["schedule_tables"] = names
+
+    # ---- 2. DDIM / DDPM step KATs (schedule.py:157-238) ----------------------------------------------
+    d = {}
+    B, T, M = 7, 5, 80
+    x = rnd((B, T, M), 11, 0, 2.0)
+    eps = rnd((B, T, M), 11, 1, 1.5)
+    t = torch.tensor([999, 749, 499, 249, 1, 0, 500])
+    t_prev = torch.tensor([749, 499, 249, 0, 0, -1, -1])
+    xp, x0 = sch.get_ddim_step(x, t, t_prev, eps, eta=0.0)
+    d.update(x=npf(x), eps=npf(eps), t=npf(t), t_prev=npf(t_prev), ddim_x_prev=npf(xp), ddim_x0=npf(x0))
+    # eta > 0: the reference draws noise with torch.randn_like right inside the call
+    torch.manual_seed(77)
+    noise = torch.randn_like(x)
+    torch.manual_seed(77)
+    xp_e, x0_e = sch.get_ddim_step(x, t, t_prev.clamp(min=0), eps, eta=0.5)
+    d.update(noise=npf(noise), ddim_eta_x_prev=npf(xp_e), ddim_eta_x0=npf(x0_e))
+    torch.manual_seed(78)
+    noise2 = torch.randn_like(x)
+    torch.manual_seed(78)
+    xd = sch.ddpm_step(x, t, eps)
+    d.update(ddpm_noise=npf(noise2), ddpm_x_prev=npf(xd))
+    np.savez_compressed(os.path.join(OUT, "steps.npz"), **d)
+
+    # ---- 3. timestep lists (inference.py:35-36) ------------------------------------------------------
+    tl = {}
+    for n in (1, 2, 3, 4, 8, 16):
+        stride = 1000 // n
+        tl[f"n{n}"] = np.array(list(range(999, 0, -stride))[:n], dtype=np.int64)
+        assert list(tl[f"n{n}"]) == sch.get_schedule_for_steps(n)
+    np.savez_compressed(os.path.join(OUT, "timesteps.npz"), **tl)
+
+    # ---- 4. per-op KATs at tiny dims (reference layer classes called directly) ------------------------
+    cfg_t = ref.CFG(hidden=32, heads=2, layers=1, attn_window_size=4, device="cpu")
+    dec = make_decoder(cfg_t, seed=3)
+    sd = dec.state_dict()
+    B, T, S = 2, 24, 12
+    d = {}
+    tt = torch.tensor([999, 10])
+    si = torch.tensor([0, 3])
+    sem = rnd_idx((B, S), cfg_t.codebook_size, 5, 0)
+    feats = rnd((B, S, cfg_t.semantic_dim), 5, 1)
+    xt = rnd((B, T, 80), 5, 2, 1.5)
+    hh = rnd((B, T, 32), 5, 3, 1.0)
+    cond = rnd((B, 32), 5, 4, 1.0)
+    ctx = rnd((B, S, 32), 5, 5, 1.0)
+    blk = dec.layers[0]
+    d.update(t=npf(tt), step_idx=npf(si), sem_idx=npf(sem), sem_features=npf(feats), x_t=npf(xt), h=npf(hh), cond=npf(cond), ctx=npf(ctx))
+    d["time_cond"] = npf(dec.time_emb(tt) + dec.step_emb(si))
+    d["time_cond_nostep"] = npf(dec.time_emb(tt))
+    d["context_tok"] = npf(dec.context_pos_emb(dec.token_emb(sem)))
+    d["context_feat"] = npf(dec.context_pos_emb(dec.sem_proj(feats)))
+    d["input_embed"] = npf(dec.pos_emb(dec.in_proj(xt)))
+    d["ada_norm1"] = npf(blk.norm1(hh, cond))
+    d["rms_norm2"] = npf(blk.norm2(hh))
+    d["self_attn"] = npf(blk.attn(hh))
+    d["cross_attn"] = npf(blk.cross_attn(hh, context=ctx))
+    d["ffn"] = npf(blk.ffn(hh))
+    d["block"] = npf(blk(hh, context=ctx, cond=cond))
+    d["final"] = npf(dec.out_proj(dec.final_norm(hh)))
+    d["forward"] = npf(dec(xt, tt, sem, si))
+    d["forward_nostep"] = npf(dec(xt, tt, sem, None))
+    d["forward_feat"] = npf(dec(xt, tt, None, si, feats))
+    np.savez_compressed(os.path.join(OUT, "tiny_ops.npz"), **d)
+
+    # depthwise-separable conv (conv.py:25-64), the reference's measured case 80 -> 160 on [2, 80, 64] plus an odd one
+    d = {}
+    for tag, (ci, co, T_, ks) in {"a": (80, 160, 64, 3), "b": (24, 40, 37, 5)}.items():
+        m = RefDSConv(ci, co, kernel_size=ks).eval()
+        m.depthwise.weight.copy_(rnd(tuple(m.depthwise.weight.shape), 9, 0, 0.6))
+        m.pointwise.weight.copy_(rnd(tuple(m.pointwise.weight.shape), 9, 1, 0.2))
+        m.pointwise.bias.copy_(rnd(tuple(m.pointwise.bias.shape), 9, 2, 0.1))
+        m.norm.weight.copy_(1.0 + rnd(tuple(m.norm.weight.shape), 9, 3, 0.2))
+        m.norm.bias.copy_(rnd(tuple(m.norm.bias.shape), 9, 4, 0.1))
+        xin = rnd((2, ci, T_), 9, 5, 1.0)
+        d.update({f"{tag}_x": npf(xin), f"{tag}_y": npf(m(xin)), f"{tag}_dw": npf(m.depthwise.weight), f"{tag}_pw": npf(m.pointwise.weight),
+                  f"{tag}_pb": npf(m.pointwise.bias), f"{tag}_gw": npf(m.norm.weight), f"{tag}_gb": npf(m.norm.bias),
+                  f"{tag}_groups": np.array(m.norm.num_groups)})
+    np.savez_compressed(os.path.join(OUT, "dsconv.npz"), **d)
+
+    # ---- 5. decoder forward at CFG() dims -------------------------------------------------------------
+    cfg = ref.CFG(device="cpu")
+    dec = make_decoder(cfg, seed=0)
+    B, T, S = 2, 64, 32
+    xt = rnd((B, T, 80), 21, 0, 1.5)
+    tt = torch.tensor([999, 10])
+    si = torch.tensor([0, 3])
+    sem = rnd_idx((B, S), cfg.codebook_size, 21, 1)
+    feats = rnd((B, S, cfg.semantic_dim), 21, 2)
+    d = dict(x_t=npf(xt), t=npf(tt), step_idx=npf(si), sem_idx=npf(sem), sem_features=npf(feats))
+    d["eps"] = npf(dec(xt, tt, sem, si))
+    d["eps_nostep"] = npf(dec(xt, tt, sem, None))
+    d["eps_feat"] = npf(dec(xt, tt, None, si, feats))
+    # ragged length (T not a multiple of the 32-frame wave tile, S odd)
+    xt2 = rnd((1, 75, 80), 21, 3, 1.5)
+    sem2 = rnd_idx((1, 37), cfg.codebook_size, 21, 4)
+    d.update(x_t_ragged=npf(xt2), sem_idx_ragged=npf(sem2), eps_ragged=npf(dec(xt2, torch.tensor([321]), sem2, torch.tensor([2]))))
+    np.savez_compressed(os.path.join(OUT, "forward_cfg.npz"), **d)
+
+    # ---- 6. end-to-end generate_mel, BASELINE config 1 (B=1, T=256, 4 steps) -----------------------------
+    def run_generate(decoder, sem_idx, seed, num_steps):
+        infer = ref.EdgeInference(cfg, sch, torch.nn.Identity(), decoder)
+        B_, S_ = sem_idx.shape
+        torch.manual_seed(seed)
+        x_T = torch.randn(B_, 2 * S_, cfg.n_mels)  # the draw generate_mel makes first (inference.py:33)
+        trace = []
+        orig = sch.get_ddim_step
+
+        def spy(x_t, t, t_prev, eps_pred, eta=0.0):
+            xp, x0 = orig(x_t, t, t_prev, eps_pred, eta)
+            trace.append((eps_pred.clone(), xp.clone(), x0.clone()))
+            return xp, x0
+
+        sch.get_ddim_step = spy
+        try:
+            torch.manual_seed(seed)
+            out = infer.generate_mel(sem_idx, num_steps=num_steps)
+        finally:
+            sch.get_ddim_step = orig
+        return x_T, out, trace
+
+    sem = rnd_idx((1, 128), cfg.codebook_size, 31, 0)
+    x_T, out, trace = run_generate(dec, sem, 123, 4)
+    d = dict(sem_idx=npf(sem), x_T=npf(x_T), out=npf(out))
+    for i, (e, xp, x0) in enumerate(trace):
+        d[f"eps{i}"], d[f"x_prev{i}"], d[f"x0_{i}"] = npf(e), npf(xp), npf(x0)
+    # default init (decoder == 0): pins the schedule / DDIM arithmetic exactly
+    dec0 = ref.EdgeDiffusionDecoder(cfg).eval()
+    x_T0, out0, _ = run_generate(dec0, sem, 123, 4)
+    assert torch.equal(x_T0, x_T)
+    d["out_default_init"] = npf(out0)
+    # other step counts on a smaller case
+    sem_s = rnd_idx((2, 24), cfg.codebook_size, 31, 1)
+    for n in (1, 2, 16):
+        xTs, outs, _ = run_generate(dec, sem_s, 7, n)
+        d[f"small_out_n{n}"] = npf(outs)
+    d["small_sem_idx"], d["small_x_T"] = npf(sem_s), npf(xTs)
+    np.savez_compressed(os.path.join(OUT, "generate_cfg1.npz"), **d)
+
+    # ---- 7. BASELINE config-3-shaped case: hidden=256, layers=8, heads=8, T=1024, S=512 (needs pos table >= 1024, F6) ----
+    cfg3 = ref.CFG(hidden=256, layers=8, heads=8, device="cpu")
+    dec3 = make_decoder(cfg3, seed=1, max_pos=1024)
+    sem3 = rnd_idx((1, 512), cfg3.codebook_size, 41, 0)
+    x3 = rnd((1, 1024, 80), 41, 1, 1.5)
+    e3 = dec3(x3, torch.tensor([600]), sem3, torch.tensor([1]))
+    np.savez_compressed(os.path.join(OUT, "forward_cfg3.npz"), x_t=npf(x3), sem_idx=npf(sem3), t=np.array([600]), step_idx=np.array([1]),
+                        eps=npf(e3))
+
+    for f in sorted(os.listdir(OUT)):
+        if f.endswith(".npz"):
+            print(f"{f}: {os.path.getsize(os.path.join(OUT, f)) / 1024:.0f} KiB")
+
+
+if __name__ == "__main__":
+    main()

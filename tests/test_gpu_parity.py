@@ -1,0 +1,266 @@
+"""GPU parity tests: the product path (Python API -> ctypes -> libedtts_hip.so -> gfx950 kernels) against the
+reference's golden vectors and the CPU oracle.  Run on the GPU box: python -m pytest tests -m gpu."""
+import pytest
+import torch
+
+from conftest import max_abs
+from edge_diffusion_tts_amd import (CFG, DepthwiseSeparableConv, DiffusionSchedule, EdgeDiffusionDecoder, EdgeInference,
+                                    synth_state_dict)
+from oracle import edtts_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+# tolerances: single forward vs the fp32 reference 1e-4 max-abs (outputs are O(1));
+# DDIM / DDPM updates bit-exact; end-to-end 1e-3 outside the t=999 amplification band.
+FWD_TOL = 1e-4
+E2E_TOL = 1e-3
+
+
+def make_decoder(cfg, seed, **kw):
+    dec = EdgeDiffusionDecoder(cfg, **kw)
+    dec.load_state_dict(synth_state_dict(cfg, seed, max_pos=dec.max_len, max_ctx_pos=dec.max_context_len))
+    return dec.to(DEV).eval()
+
+
+def cu(t):
+    return None if t is None else t.to(DEV)
+
+
+def test_library_is_loaded():
+    from edge_diffusion_tts_amd import native
+    assert native.lib().edtts_version() >= 100
+    assert torch.cuda.is_available()
+
+
+def test_ddim_ddpm_bit_exact(golden):
+    g = golden("steps")
+    sch = DiffusionSchedule(1000).to(DEV)
+    xp, x0 = sch.get_ddim_step(cu(g["x"]), cu(g["t"]), cu(g["t_prev"]), cu(g["eps"]), eta=0.0)
+    assert torch.equal(xp.cpu(), g["ddim_x_prev"]) and torch.equal(x0.cpu(), g["ddim_x0"])
+    xp, x0 = sch.get_ddim_step(cu(g["x"]), cu(g["t"]), cu(g["t_prev"].clamp(min=0)), cu(g["eps"]), eta=0.5, noise=cu(g["noise"]))
+    assert torch.equal(xp.cpu(), g["ddim_eta_x_prev"]) and torch.equal(x0.cpu(), g["ddim_eta_x0"])
+    xd = sch.ddpm_step(cu(g["x"]), cu(g["t"]), cu(g["eps"]), noise=cu(g["ddpm_noise"]))
+    assert torch.equal(xd.cpu(), g["ddpm_x_prev"])
+
+
+def test_alpha_bar_table_matches_golden(golden):
+    """The one table the hot path reads, built by this host's CPU, equals the reference's (bit-exact)."""
+    assert torch.equal(DiffusionSchedule(1000).alpha_bar, golden("schedule_tables")["alpha_bar"])
+
+
+def test_ddim_large_vs_oracle():
+    """Full-size DDIM update against the oracle evaluated on this box's host CPU.  The committed golden vectors are
+    matched bit-exactly (test above); here 1 ulp of slack is allowed because torch.sqrt on the GPU box's host CPU is
+    not correctly rounded for every input (measured: the kernel equals the exactly-rounded value)."""
+    gen = torch.Generator().manual_seed(1)
+    B, T, M = 16, 512, 80
+    x, eps = torch.randn(B, T, M, generator=gen) * 2, torch.randn(B, T, M, generator=gen)
+    t = torch.randint(0, 1000, (B,), generator=gen)
+    tp = (t - 250).clamp(min=-1)
+    sch = DiffusionSchedule(1000).to(DEV)
+    xp, x0 = sch.get_ddim_step(cu(x), cu(t), cu(tp), cu(eps))
+    rxp, rx0 = O.ddim_step(O.schedule_tables(1000)["alpha_bar"], x, t, tp, eps)
+    torch.testing.assert_close(xp.cpu(), rxp, rtol=1e-6, atol=1e-6)   # SURVEY.md section 8d (ii); values are O(1)
+    torch.testing.assert_close(x0.cpu(), rx0, rtol=1e-6, atol=1e-6)
+    assert float(x0.abs().max()) <= 3.0
+
+
+def test_tiny_forward(golden):
+    g = golden("tiny_ops")
+    cfg = CFG(hidden=32, heads=2, layers=1, attn_window_size=4, device=DEV)
+    dec = make_decoder(cfg, 3)
+    e = dec(cu(g["x_t"]), cu(g["t"]), cu(g["sem_idx"]), cu(g["step_idx"])).cpu()
+    assert max_abs(e, g["forward"]) < FWD_TOL
+    e = dec(cu(g["x_t"]), cu(g["t"]), cu(g["sem_idx"]), None).cpu()
+    assert max_abs(e, g["forward_nostep"]) < FWD_TOL
+    e = dec(cu(g["x_t"]), cu(g["t"]), None, cu(g["step_idx"]), cu(g["sem_features"])).cpu()
+    assert max_abs(e, g["forward_feat"]) < FWD_TOL
+
+
+def test_forward_cfg_dims(golden):
+    g = golden("forward_cfg")
+    cfg = CFG(device=DEV)
+    dec = make_decoder(cfg, 0)
+    e = dec(cu(g["x_t"]), cu(g["t"]), cu(g["sem_idx"]), cu(g["step_idx"])).cpu()
+    assert max_abs(e, g["eps"]) < FWD_TOL
+    assert max_abs(dec(cu(g["x_t"]), cu(g["t"]), cu(g["sem_idx"]), None).cpu(), g["eps_nostep"]) < FWD_TOL
+    assert max_abs(dec(cu(g["x_t"]), cu(g["t"]), None, cu(g["step_idx"]), cu(g["sem_features"])).cpu(), g["eps_feat"]) < FWD_TOL
+    # ragged lengths: T = 75 (not a multiple of the 32-frame tile), S = 37
+    e = dec(cu(g["x_t_ragged"]), torch.tensor([321], device=DEV), cu(g["sem_idx_ragged"]), torch.tensor([2], device=DEV)).cpu()
+    assert max_abs(e, g["eps_ragged"]) < FWD_TOL
+
+
+def test_forward_matches_fp64_arbiter(golden):
+    g = golden("forward_cfg")
+    cfg = CFG(device=DEV)
+    dec = make_decoder(cfg, 0)
+    sd = synth_state_dict(cfg, 0)
+    e64 = O.decoder_forward(O.cast_sd(sd, torch.float64), g["x_t"].double(), g["t"], g["sem_idx"], g["step_idx"])
+    e = dec(cu(g["x_t"]), cu(g["t"]), cu(g["sem_idx"]), cu(g["step_idx"])).cpu()
+    ours, theirs = max_abs(e, e64), max_abs(g["eps"], e64)
+    assert ours < 2e-5, (ours, theirs)  # same order as the reference's own fp32-vs-fp64 distance
+
+
+def test_forward_cfg3_shape(golden):
+    g = golden("forward_cfg3")
+    cfg = CFG(hidden=256, layers=8, heads=8, device=DEV)
+    dec = make_decoder(cfg, 1, max_len=1024)
+    e = dec(cu(g["x_t"]), cu(g["t"]), cu(g["sem_idx"]), cu(g["step_idx"])).cpu()
+    assert max_abs(e, g["eps"]) < FWD_TOL
+
+
+def test_missing_context_raises():
+    cfg = CFG(device=DEV)
+    dec = make_decoder(cfg, 0)
+    with pytest.raises(ValueError):
+        dec(torch.zeros(1, 32, 80, device=DEV), torch.zeros(1, dtype=torch.long, device=DEV))
+
+
+def test_length_limits_raise():
+    cfg = CFG(device=DEV)
+    dec = make_decoder(cfg, 0)
+    with pytest.raises(RuntimeError):  # T > 1000 rows of pos_emb
+        dec(torch.zeros(1, 1001, 80, device=DEV), torch.zeros(1, dtype=torch.long, device=DEV), torch.zeros(1, 8, dtype=torch.long, device=DEV))
+    infer = EdgeInference(cfg, DiffusionSchedule(1000).to(DEV), None, dec)
+    with pytest.raises((IndexError, RuntimeError)):  # num_steps > 16 rows of step_emb
+        infer.generate_mel(torch.zeros(1, 8, dtype=torch.long, device=DEV), num_steps=17)
+
+
+def test_cpu_tensors_fail_loudly():
+    from edge_diffusion_tts_amd.native import EdttsError
+    cfg = CFG(device=DEV)
+    dec = make_decoder(cfg, 0)
+    with pytest.raises(EdttsError):
+        dec(torch.zeros(1, 32, 80), torch.zeros(1, dtype=torch.long), torch.zeros(1, 16, dtype=torch.long))
+    with pytest.raises(EdttsError):
+        DiffusionSchedule(1000).get_ddim_step(torch.zeros(1, 4, 80), torch.zeros(1, dtype=torch.long), torch.zeros(1, dtype=torch.long), torch.zeros(1, 4, 80))
+
+
+def e2e_check(ours, ref, what):
+    """End-to-end criterion (DESIGN.md "Parity protocol").  At t=999 x0 = (x - s*eps)/1.558e-5 amplifies any
+    eps rounding difference 64171x before the clamp, and the few unclamped elements then perturb their neighbours through
+    the later steps' attention, so no fp32 implementation with a different summation order meets 1e-3 on EVERY element
+    (the reference's own fp32 vs fp64 run differs by up to 6.9e-3 on this input).  Required: >= 99.7 % of the elements
+    within 1e-3, none beyond 0.1, and the median error at rounding level."""
+    err = (ours.double() - ref.double()).abs().flatten()
+    frac_bad = float((err > E2E_TOL).double().mean())
+    print(f"{what}: max {float(err.max()):.2e} median {float(err.median()):.2e} p99.9 {float(err.quantile(0.999)):.2e} "
+          f"frac>1e-3 {frac_bad:.2e}")
+    assert frac_bad <= 3e-3, (what, frac_bad)
+    assert float(err.max()) < 0.1, (what, float(err.max()))
+    assert float(err.median()) < 2e-5, (what, float(err.median()))
+
+
+def test_generate_cfg1(golden):
+    """BASELINE config 1: CFG() defaults, B=1, T=256, 4-step DDIM, against the reference's CPU run."""
+    g = golden("generate_cfg1")
+    cfg = CFG(device=DEV)
+    dec = make_decoder(cfg, 0)
+    sch = DiffusionSchedule(cfg.diff_steps).to(DEV)
+    infer = EdgeInference(cfg, sch, torch.nn.Identity(), dec)
+    out = infer.generate_mel(cu(g["sem_idx"]), 4, x_T=cu(g["x_T"])).cpu()
+    assert out.shape == g["out"].shape and float(out.abs().max()) <= 3.0
+    e2e_check(out, g["out"], "generate_mel cfg1 vs reference fp32")
+    # the same comparison against the fp64 arbiter, next to the reference's own fp32-vs-fp64 distance
+    sd64 = O.cast_sd(synth_state_dict(cfg, 0), torch.float64)
+    out64 = O.generate_mel(sd64, O.schedule_tables(1000, torch.float64)["alpha_bar"], g["sem_idx"], g["x_T"].double(), 4)
+    e2e_check(out, out64, "generate_mel cfg1 vs fp64 arbiter")
+    e2e_check(g["out"], out64, "reference fp32 vs fp64 arbiter (context)")
+    # teacher-forced: every step fed the reference's own x_t matches to the single-forward tolerance, and the DDIM
+    # update applied to the reference's eps is bit-exact
+    for i, t in enumerate([999, 749, 499, 249]):
+        xin = g["x_T"] if i == 0 else g[f"x_prev{i - 1}"]
+        tt = torch.full((1,), t, device=DEV)
+        eps = dec(cu(xin), tt, cu(g["sem_idx"]), torch.full((1,), i, device=DEV)).cpu()
+        assert max_abs(eps, g[f"eps{i}"]) < FWD_TOL, i
+        xp, x0 = sch.get_ddim_step(cu(xin), tt, torch.full((1,), max(t - 250, 0), device=DEV), cu(g[f"eps{i}"]))
+        assert torch.equal(xp.cpu(), g[f"x_prev{i}"]) and torch.equal(x0.cpu(), g[f"x0_{i}"]), i
+    # other step counts
+    for n in (1, 2, 16):
+        o = infer.generate_mel(cu(g["small_sem_idx"]), n, x_T=cu(g["small_x_T"])).cpu()
+        e2e_check(o, g[f"small_out_n{n}"], f"generate_mel {n}-step vs reference fp32")
+
+
+def test_generate_default_init_exact(golden):
+    """Reference default init: out_proj is zero so eps == 0 and the result is pure DDIM arithmetic -> exact."""
+    g = golden("generate_cfg1")
+    cfg = CFG(device=DEV)
+    sd = synth_state_dict(cfg, 0)
+    sd["out_proj.weight"].zero_()
+    sd["out_proj.bias"].zero_()
+    dec = EdgeDiffusionDecoder(cfg)
+    dec.load_state_dict(sd)
+    dec = dec.to(DEV).eval()
+    infer = EdgeInference(cfg, DiffusionSchedule(cfg.diff_steps).to(DEV), torch.nn.Identity(), dec)
+    out = infer.generate_mel(cu(g["sem_idx"]), 4, x_T=cu(g["x_T"])).cpu()
+    assert torch.equal(out, g["out_default_init"])
+
+
+def test_generate_equals_stepwise_api():
+    """The fused loop (edtts_generate) == decoder.forward + schedule.get_ddim_step called step by step, bitwise."""
+    cfg = CFG(device=DEV)
+    dec = make_decoder(cfg, 0)
+    sch = DiffusionSchedule(cfg.diff_steps).to(DEV)
+    infer = EdgeInference(cfg, sch, torch.nn.Identity(), dec)
+    gen = torch.Generator().manual_seed(3)
+    B, S = 3, 40
+    sem = torch.randint(0, 512, (B, S), generator=gen).to(DEV)
+    x = torch.randn(B, 2 * S, 80, generator=gen).to(DEV)
+    fused = infer.generate_mel(sem, 4, x_T=x)
+    stride = 250
+    for i, t in enumerate([999, 749, 499, 249]):
+        tt = torch.full((B,), t, device=DEV)
+        eps = dec(x, tt, sem, torch.full((B,), i, device=DEV))
+        x, x0 = sch.get_ddim_step(x, tt, torch.full((B,), max(t - stride, 0), device=DEV), eps)
+    assert torch.equal(fused, x0)
+
+
+def test_deterministic_and_batch_invariant():
+    """Run twice -> bitwise equal (no races); an utterance alone == the same utterance inside a batch (no cross-batch op)."""
+    cfg = CFG(device=DEV)
+    dec = make_decoder(cfg, 0)
+    infer = EdgeInference(cfg, DiffusionSchedule(cfg.diff_steps).to(DEV), torch.nn.Identity(), dec)
+    gen = torch.Generator().manual_seed(9)
+    B, S = 8, 64
+    sem = torch.randint(0, 512, (B, S), generator=gen).to(DEV)
+    x = torch.randn(B, 2 * S, 80, generator=gen).to(DEV)
+    a = infer.generate_mel(sem, 4, x_T=x)
+    b = infer.generate_mel(sem, 4, x_T=x)
+    assert torch.equal(a, b)
+    solo = infer.generate_mel(sem[5:6].contiguous(), 4, x_T=x[5:6].contiguous())
+    assert torch.equal(solo[0], a[5])
+
+
+def test_full_size_config2_properties():
+    """BASELINE config 2 (B=256, T=512): too big for the oracle in seconds -> size-independent properties:
+    slices of the big batch equal the same utterances run in a small batch (bitwise), outputs clamped and finite."""
+    cfg = CFG(device=DEV)
+    dec = make_decoder(cfg, 0)
+    infer = EdgeInference(cfg, DiffusionSchedule(cfg.diff_steps).to(DEV), torch.nn.Identity(), dec)
+    gen = torch.Generator().manual_seed(2)
+    B, S = 256, 256
+    sem = torch.randint(0, 512, (B, S), generator=gen).to(DEV)
+    x = torch.randn(B, 2 * S, 80, generator=gen).to(DEV)
+    big = infer.generate_mel(sem, 4, x_T=x)
+    assert big.shape == (B, 512, 80) and bool(torch.isfinite(big).all()) and float(big.abs().max()) <= 3.0
+    idx = [0, 131, 255]
+    small = infer.generate_mel(sem[idx].contiguous(), 4, x_T=x[idx].contiguous())
+    assert torch.equal(small, big[idx])
+    # and one of them against the CPU oracle (outside the amplification band)
+    sd = synth_state_dict(cfg, 0)
+    ref = O.generate_mel(sd, O.schedule_tables(1000)["alpha_bar"], sem[131:132].cpu(), x[131:132].cpu(), 4)
+    e2e_check(big[131:132].cpu(), ref, "config-2 utterance 131 vs oracle")
+
+
+def test_dsconv(golden):
+    g = golden("dsconv")
+    for tag in ("a", "b"):
+        ci, co, ks = g[f"{tag}_x"].shape[1], g[f"{tag}_pw"].shape[0], g[f"{tag}_dw"].shape[-1]
+        m = DepthwiseSeparableConv(ci, co, kernel_size=ks)
+        m.load_state_dict({"depthwise.weight": g[f"{tag}_dw"], "pointwise.weight": g[f"{tag}_pw"], "pointwise.bias": g[f"{tag}_pb"],
+                           "norm.weight": g[f"{tag}_gw"], "norm.bias": g[f"{tag}_gb"]})
+        m = m.to(DEV)
+        assert m.groups == int(g[f"{tag}_groups"])
+        y = m(cu(g[f"{tag}_x"])).cpu()
+        assert max_abs(y, g[f"{tag}_y"]) < 1e-5

@@ -1,0 +1,148 @@
+"""CPU-only tests of the host layer: config surface, schedule tables, weight recipe, C-ABI library loading and
+symbol export, error behaviour without a GPU.  No kernel is launched here."""
+import ctypes
+import dataclasses
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import REPO
+from edge_diffusion_tts_amd import CFG, DiffusionSchedule, EdgeDiffusionDecoder, EdgeInference, TrainPhase, native, synth_state_dict
+from edge_diffusion_tts_amd.synth import decoder_shapes, hash_uniform
+
+
+def test_cfg_defaults_and_roundtrip():
+    cfg = CFG(device="cpu")
+    # the fields the sampler path reads and their reference defaults
+    assert (cfg.n_mels, cfg.diff_steps, cfg.hidden, cfg.layers, cfg.heads, cfg.ffn_mult) == (80, 1000, 160, 4, 4, 2)
+    assert (cfg.attn_window_size, cfg.codebook_size, cfg.semantic_dim, cfg.use_adaln, cfg.dropout) == (64, 512, 128, True, 0.2)
+    assert cfg.segment_len == 32000 and cfg.inference_steps == 4 and cfg.phase is TrainPhase.DIFFUSION
+    assert cfg.ckpt_path.endswith("checkpoint_latest.pt") and os.path.isdir(cfg.out_dir) and os.path.isdir(cfg.data_root)
+    d = cfg.to_dict()
+    assert d["phase"] == "diffusion" and set(d) == {f.name for f in dataclasses.fields(CFG)}
+    d["unknown_key"] = 1
+    cfg2 = CFG.from_dict(d)
+    assert cfg2.phase is TrainPhase.DIFFUSION and cfg2.to_dict() == cfg.to_dict()
+    assert len(dataclasses.fields(CFG)) == 57
+
+
+def test_schedule_tables_match_reference(golden):
+    g = golden("schedule_tables")
+    sch = DiffusionSchedule(1000)
+    for name in DiffusionSchedule.TABLE_NAMES:
+        assert torch.equal(getattr(sch, name), g[name]), name
+    assert sch.get_schedule_for_steps(4) == [999, 749, 499, 249]
+    tl = golden("timesteps")
+    for n in (1, 2, 3, 4, 8, 16):
+        assert sch.get_schedule_for_steps(n) == tl[f"n{n}"].tolist()
+
+
+def test_schedule_light_algebra_roundtrip():
+    sch = DiffusionSchedule(1000)
+    g = torch.Generator().manual_seed(0)
+    x0 = torch.randn(3, 5, 80, generator=g)
+    t = torch.tensor([10, 500, 900])
+    xt, noise = sch.q_sample(x0, t, torch.randn(3, 5, 80, generator=g))
+    assert torch.allclose(sch.predict_x0_from_eps(xt, t, noise), x0, atol=2e-3)
+    v = sch.get_v_target(x0, noise, t)
+    assert torch.allclose(sch.predict_x0_from_v(xt, t, v), x0, atol=1e-4)
+    assert torch.allclose(sch.predict_eps_from_v(xt, t, v), noise, atol=1e-4)
+
+
+def test_ddim_coefficients_are_exactly_rounded():
+    sch = DiffusionSchedule(1000)
+    for t, tp in ((999, 749), (749, 499), (249, 0), (315, 65), (5, -1)):
+        c = sch.ddim_coefficients(t, tp)
+        ab = np.float64(sch.alpha_bar[t].item())
+        abp = np.float64(sch.alpha_bar[tp].item()) if tp >= 0 else np.float64(1.0)
+        assert c[0] == float(np.float32(np.sqrt(np.float64(np.float32(1.0 - ab)))))
+        assert c[1] == float(np.float32(np.sqrt(ab))) and c[2] == float(np.float32(np.sqrt(abp)))
+        assert c[3] == float(np.float32(np.sqrt(np.float64(np.float32(1.0 - abp)))))
+
+
+def test_synth_weights_are_portable_and_complete():
+    cfg = CFG(device="cpu")
+    a, b = synth_state_dict(cfg, 0), synth_state_dict(cfg, 0)
+    assert list(a) == list(decoder_shapes(cfg)) and all(torch.equal(a[k], b[k]) for k in a)
+    assert not torch.equal(a["in_proj.weight"], synth_state_dict(cfg, 1)["in_proj.weight"])
+    # known answer of the counter hash (guards against platform-dependent integer behaviour)
+    assert abs(float(hash_uniform((3,), 0, 0)[1]) - (-0.6672071210646784)) < 1e-15
+    # tensors the reference zero-initialises are non-zero here
+    for k in ("out_proj.weight", "out_proj.bias", "layers.0.norm1.proj.weight", "layers.3.norm3.proj.bias"):
+        assert float(a[k].abs().max()) > 0
+    assert sum(v.numel() for k, v in a.items() if not k.endswith(".pe")) == 1983440
+
+
+def test_decoder_state_dict_contract():
+    cfg = CFG(device="cpu")
+    dec = EdgeDiffusionDecoder(cfg)
+    keys = list(dec.state_dict().keys())
+    assert keys == list(decoder_shapes(cfg).keys())
+    assert sum(p.numel() for p in dec.parameters()) == 1983440
+    # reference default init: out_proj and the AdaLN projections are zero (decoder.py:63-64, transformer.py:61-62)
+    sd = dec.state_dict()
+    assert float(sd["out_proj.weight"].abs().max()) == 0 and float(sd["layers.2.norm1.proj.weight"].abs().max()) == 0
+    assert float(sd["layers.1.norm2.weight"].min()) == 1.0 and sd["pos_emb.pe"].shape == (1000, 160)
+    res = dec.load_state_dict(synth_state_dict(cfg, 0))
+    assert not res.missing_keys and not res.unexpected_keys
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(REPO, "include", "edtts.h")).read()
+    declared = set(re.findall(r"\b(edtts_[a-z_0-9]+)\s*\(", header))
+    assert declared == set(native.EXPORTED_SYMBOLS)
+    L = ctypes.CDLL(native.LIB_PATH)
+    for sym in declared:
+        assert hasattr(L, sym), sym
+    lib = native.lib()
+    assert lib.edtts_version() == 100
+
+
+def test_slot_names_cover_the_state_dict():
+    cfg = CFG(device="cpu")
+    names = native.slot_names(cfg.layers)
+    keys = set(decoder_shapes(cfg).keys()) | {"time_freqs"}
+    assert set(names) == keys and len(names) == len(keys)
+
+
+def test_size_queries_and_unsupported_dims():
+    cfg = CFG(device="cpu")
+    dec = EdgeDiffusionDecoder(cfg)
+    assert native.packed_bytes(dec.dims()) > 4 * 1983440
+    small = native.workspace_bytes(dec.dims(), 1, 256, 128, 4)
+    big = native.workspace_bytes(dec.dims(), 256, 512, 256, 4)
+    assert big > 100 * small > 0
+    bad = EdgeDiffusionDecoder(CFG(hidden=96, heads=4, device="cpu"))   # 96/4 = 24: head_dim % 16 == 8 but no instance
+    ws = native.workspace_bytes(bad.dims(), 1, 32, 16, 1)                # layout queries work for any hidden % 32 == 0
+    assert ws > 0
+    with pytest.raises(native.EdttsError, match="need hidden"):
+        native.workspace_bytes(EdgeDiffusionDecoder(CFG(hidden=100, heads=4, device="cpu")).dims(), 1, 32, 16, 1)
+
+
+def test_no_cpu_fallback():
+    cfg = CFG(device="cpu")
+    dec = EdgeDiffusionDecoder(cfg)
+    with pytest.raises(ValueError):
+        dec(torch.zeros(1, 32, 80), torch.zeros(1, dtype=torch.long))
+    with pytest.raises(native.EdttsError, match="HIP device"):
+        dec(torch.zeros(1, 32, 80), torch.zeros(1, dtype=torch.long), torch.zeros(1, 16, dtype=torch.long))
+    sch = DiffusionSchedule(1000)
+    with pytest.raises(native.EdttsError, match="HIP device"):
+        sch.get_ddim_step(torch.zeros(1, 4, 80), torch.zeros(1, dtype=torch.long), torch.zeros(1, dtype=torch.long), torch.zeros(1, 4, 80))
+    with pytest.raises(native.EdttsError, match="HIP device"):
+        sch.ddpm_step(torch.zeros(1, 4, 80), torch.zeros(1, dtype=torch.long), torch.zeros(1, 4, 80))
+    infer = EdgeInference(cfg, sch, None, dec)
+    with pytest.raises(native.EdttsError):
+        infer.generate_mel(torch.zeros(1, 16, dtype=torch.long), 4)
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(REPO, "edge-diffusion-tts_amd", "edge_diffusion_tts_amd")
+    for f in sorted(os.listdir(pkg)):
+        if f.endswith(".py"):
+            src = open(os.path.join(pkg, f)).read()
+            assert not re.search(r"^\s*(from|import)\s+\.*oracle", src, re.M), f
+            assert "edtts_oracle" not in src, f
