@@ -56,16 +56,25 @@ EDTTS_DEV void stg4(float* p, f4 v) { *reinterpret_cast<f4*>(p) = v; }
 EDTTS_DEV float sqrt_rn(float x) { return (float)sqrt((double)x); }
 EDTTS_DEV float div_rn(float a, float b) { return (float)((double)a / (double)b); }
 
-// reduce a per-lane value over the four lane groups that hold the same frame (lanes fq, fq+16, fq+32, fq+48)
+// reduce a per-lane value over the four lane groups that hold the same frame (lanes fq, fq+16, fq+32, fq+48).
+// v_permlane16_swap / v_permlane32_swap exchange 16-lane rows / 32-lane halves in the VALU (no LDS crossbar trip as
+// ds_bpermute would take): after swap(x, x) the two results hold {own, partner} in some order, and the ops are
+// commutative.
 EDTTS_DEV float group_sum(float v) {
-  v += __shfl_xor(v, 16);
-  v += __shfl_xor(v, 32);
-  return v;
+  unsigned u = __float_as_uint(v);
+  auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  u = __float_as_uint(v);
+  auto b = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
 EDTTS_DEV float group_max(float v) {
-  v = fmaxf(v, __shfl_xor(v, 16));
-  v = fmaxf(v, __shfl_xor(v, 32));
-  return v;
+  unsigned u = __float_as_uint(v);
+  auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  v = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+  u = __float_as_uint(v);
+  auto b = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
 }
 EDTTS_DEV float hsum(f4 v) { return (v[0] + v[1]) + (v[2] + v[3]); }
 EDTTS_DEV float hmax(f4 v) { return fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])); }
@@ -89,6 +98,9 @@ struct FragRing {
   EDTTS_DEV f4 take(int i) {
     f4 a = r[i];
     r[i] = p[(N + i) * 64];
+    // hipcc's pre-RA scheduler otherwise sinks this load down to its use one phase later (register-pressure
+    // heuristic), turning the prefetch into a load->wait->MFMA sequence; pin the issue point.
+    __builtin_amdgcn_sched_barrier(0);
     return a;
   }
   EDTTS_DEV void advance() { p += N * 64; }
@@ -197,13 +209,22 @@ EDTTS_DEV float silu(float g) { return g / (1.0f + __expf(-g)); }
 //   SELF : keys are frames of the same utterance, band |i-j| <= window (layers/attention.py:27-30,108-112)
 //   !SELF: keys are the S context tokens, no mask (layers/mla.py:158-179)
 // ---------------------------------------------------------------------------------------------------------
+constexpr int kChunk = 2;  // key tiles (16 keys each) per online-softmax step
+
+template <class C>
+struct KVFrag {  // MFMA A operands of one chunk of key tiles, for one head
+  f4 ka[kChunk][C::DFULL > 0 ? C::DFULL : 1];
+  f2 kr[kChunk];
+};
+
 template <class C, bool SELF, class QLoad>
 EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, const float* __restrict__ VTb, int ldv,
                                int nkeys, int window, int m0, int lane, FragRing<C::HT>& ring, f4 (&h)[C::HT][2]) {
-  constexpr int DH = C::DH, DFULL = C::DFULL, DREM = C::DREM, DT = C::DT, H = C::H;
+  constexpr int DH = C::DH, DFULL = C::DFULL, DREM = C::DREM, DT = C::DT, H = C::H, CH = kChunk;
   const int fq = lane & 15, g = lane >> 4;
   // softmax in base 2: p = 2^((s - m) * c), c = log2(e) / sqrt(d)
   const float c2 = 1.4426950408889634f * rsqrtf((float)DH);
+  const float NEG_INF = -__builtin_inff();
   int kt_lo, kt_hi;
   if (SELF && window >= 0) {
     const int lo = m0 - window;
@@ -215,6 +236,58 @@ EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, cons
     kt_lo = 0;
     kt_hi = (nkeys + 15) >> 4;
   }
+  const int nchunk = (kt_hi - kt_lo + CH - 1) / CH;
+  const int klim = (kt_hi << 4) < nkeys ? (kt_hi << 4) : nkeys;  // keys >= klim are never valid
+  // per-lane band limits on d = key - query:  lo_d <= d <= hi_d   (one unsigned compare per score)
+  int lo_d[2], span[2];
+#pragma unroll
+  for (int ft = 0; ft < 2; ++ft) {
+    const int qi = m0 + 16 * ft + fq;
+    int lo = -(1 << 28), hi = klim - 1 - qi;
+    if (SELF && window >= 0) {
+      lo = -window;
+      hi = hi < window ? hi : window;
+    }
+    lo_d[ft] = lo;
+    span[ft] = hi - lo;  // negative -> nothing valid
+  }
+
+  // loads of one chunk's K fragments (tile index clamped: tiles past kt_hi are fully masked by klim)
+  auto load_k = [&](int hd, int c, KVFrag<C>& f) {
+#pragma unroll
+    for (int t = 0; t < CH; ++t) {
+      int kt = kt_lo + c * CH + t;
+      kt = kt < kt_hi ? kt : kt_hi - 1;
+      const float* kp = Kb + (size_t)((kt << 4) + fq) * H + hd * DH;
+#pragma unroll
+      for (int a = 0; a < DFULL; ++a) f.ka[t][a] = ldg4(kp + 16 * a + 4 * g);
+      if (DREM) f.kr[t] = ldg2(kp + 16 * DFULL + 2 * g);
+    }
+  };
+  // S^T chunk = K Q^T for both query tiles, accumulators interleaved (ft 0/1 alternate -> no dependent back-to-back MFMAs)
+  auto qk = [&](const KVFrag<C>& f, const f4 (&qa)[2][DFULL > 0 ? DFULL : 1], const f2 (&qr)[2], f4 (&S)[CH][2]) {
+#pragma unroll
+    for (int t = 0; t < CH; ++t) S[t][0] = S[t][1] = splat(0.f);
+#pragma unroll
+    for (int a = 0; a < DFULL; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int t = 0; t < CH; ++t) {
+          S[t][0] = EDTTS_MFMA(f.ka[t][a][b], qa[0][a][b], S[t][0]);
+          S[t][1] = EDTTS_MFMA(f.ka[t][a][b], qa[1][a][b], S[t][1]);
+        }
+    if (DREM) {
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int t = 0; t < CH; ++t) {
+          S[t][0] = EDTTS_MFMA(f.kr[t][b], qr[0][b], S[t][0]);
+          S[t][1] = EDTTS_MFMA(f.kr[t][b], qr[1][b], S[t][1]);
+        }
+    }
+  };
+
   for (int hd = 0; hd < C::HEADS; ++hd) {
     // ---- q fragments of this head (B operand): lane (fq,g) holds q[query][hd*DH + 16a + 4g + b] -------------
     f4 qa[2][DFULL > 0 ? DFULL : 1];
@@ -230,65 +303,74 @@ EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, cons
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) O[dt][0] = O[dt][1] = splat(0.f);
 
-    for (int kt = kt_lo; kt < kt_hi; ++kt) {
-      const int k0 = kt << 4;
-      // A operands: K rows (keys on fq) and V^T rows (head features on fq)
-      const float* kp = Kb + (size_t)(k0 + fq) * H + hd * DH;
-      f4 ka[DFULL > 0 ? DFULL : 1];
-      f2 kr;
-#pragma unroll
-      for (int a = 0; a < DFULL; ++a) ka[a] = ldg4(kp + 16 * a + 4 * g);
-      if (DREM) kr = ldg2(kp + 16 * DFULL + 2 * g);
-      f4 va[DT];
-#pragma unroll
-      for (int dt = 0; dt < DT; ++dt) va[dt] = ldg4(VTb + (size_t)(hd * DH + 16 * dt + fq) * ldv + k0 + 4 * g);
+    KVFrag<C> kcur, knext;
+    f4 Scur[CH][2], Snext[CH][2];
+    load_k(hd, 0, kcur);
+    load_k(hd, nchunk > 1 ? 1 : 0, knext);
+    __builtin_amdgcn_sched_barrier(0);
+    qk(kcur, qa, qr, Scur);
 
+    for (int c = 0; c < nchunk; ++c) {
+      // V^T fragments of this chunk (needed after the softmax) and K fragments two chunks ahead
+      f4 va[CH][DT];
+#pragma unroll
+      for (int t = 0; t < CH; ++t) {
+        int kt = kt_lo + c * CH + t;
+        kt = kt < kt_hi ? kt : kt_hi - 1;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) va[t][dt] = ldg4(VTb + (size_t)(hd * DH + 16 * dt + fq) * ldv + (kt << 4) + 4 * g);
+      }
+      kcur = knext;
+      load_k(hd, c + 2 < nchunk ? c + 2 : nchunk - 1, knext);
+      __builtin_amdgcn_sched_barrier(0);
+      // scores of the NEXT chunk: independent MFMA work the scheduler can overlap with this chunk's softmax VALU
+      // (on the last chunk this recomputes a clamped chunk whose result is unused)
+      qk(kcur, qa, qr, Snext);
+      // ---- online softmax of the current chunk ----------------------------------------------------------------
+      const int k0 = (kt_lo + c * CH) << 4;
+      f4 P[CH][2];
 #pragma unroll
       for (int ft = 0; ft < 2; ++ft) {
-        const int qi = m0 + 16 * ft + fq;  // this lane's query frame
-        if (SELF && window >= 0) {
-          // skip (wave-uniform) key tiles entirely outside this query tile's band
-          const int q0 = m0 + 16 * ft;
-          if (k0 + 15 < q0 - window || k0 > q0 + 15 + window) continue;
-        }
-        f4 s = splat(0.f);
+        const int d0 = k0 + 4 * g - (m0 + 16 * ft + fq) - lo_d[ft];  // (key - query - lo_d) of r = 0, tile 0
+        float mx = NEG_INF;
 #pragma unroll
-        for (int a = 0; a < DFULL; ++a)
+        for (int t = 0; t < CH; ++t)
 #pragma unroll
-          for (int b = 0; b < 4; ++b) s = EDTTS_MFMA(ka[a][b], qa[ft][a][b], s);
-        if (DREM) {
-          s = EDTTS_MFMA(kr[0], qr[ft][0], s);
-          s = EDTTS_MFMA(kr[1], qr[ft][1], s);
-        }
-        // s[r] = q_qi . k_(k0+4g+r); mask, online softmax
-        bool ok[4];
-        f4 s2;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int kj = k0 + 4 * g + r;
-          bool v = kj < nkeys;
-          if (SELF && window >= 0) {
-            const int d = kj - qi;
-            v = v && (d <= window) && (d >= -window);
+          for (int r = 0; r < 4; ++r) {
+            const bool ok = (unsigned)(d0 + 16 * t + r) <= (unsigned)span[ft] && span[ft] >= 0;
+            const float v = ok ? Scur[t][ft][r] * c2 : NEG_INF;
+            Scur[t][ft][r] = v;
+            mx = fmaxf(mx, v);
           }
-          ok[r] = v;
-          s2[r] = v ? s[r] * c2 : -1e30f;
-        }
-        const float mx = group_max(hmax(s2));
-        const float mnew = fmaxf(mrun[ft], mx);
+        mx = group_max(mx);
+        const float mnew = fmaxf(mrun[ft], mx);  // mrun starts at a finite -1e30, so exp2(-inf - mnew) = 0, never NaN
         const float alpha = fast_exp2(mrun[ft] - mnew);
         mrun[ft] = mnew;
-        f4 p;
+        float ps = 0.f;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) p[r] = ok[r] ? fast_exp2(s2[r] - mnew) : 0.f;
-        lrun[ft] = lrun[ft] * alpha + hsum(p);
+        for (int t = 0; t < CH; ++t) {
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt) {
-          f4 o = O[dt][ft] * alpha;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) o = EDTTS_MFMA(va[dt][r], p[r], o);
-          O[dt][ft] = o;
+          for (int r = 0; r < 4; ++r) P[t][ft][r] = fast_exp2(Scur[t][ft][r] - mnew);
+          ps += hsum(P[t][ft]);
         }
+        lrun[ft] = lrun[ft] * alpha + ps;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) O[dt][ft] *= alpha;
+      }
+      // ---- O^T += V^T P^T : DT x 2 independent accumulators, r outermost -------------------------------------------
+#pragma unroll
+      for (int t = 0; t < CH; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int dt = 0; dt < DT; ++dt) {
+            O[dt][0] = EDTTS_MFMA(va[t][dt][r], P[t][0][r], O[dt][0]);
+            O[dt][1] = EDTTS_MFMA(va[t][dt][r], P[t][1][r], O[dt][1]);
+          }
+#pragma unroll
+      for (int t = 0; t < CH; ++t) {
+        Scur[t][0] = Snext[t][0];
+        Scur[t][1] = Snext[t][1];
       }
     }
     // ---- normalise and project: h[nt] += Wo[:, head features] . O ------------------------------------------

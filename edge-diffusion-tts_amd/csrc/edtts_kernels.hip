@@ -2,7 +2,7 @@
 //
 // Kernel inventory (all fp32, MFMA = v_mfma_f32_16x16x4_f32, see edtts_device.h for the register data model):
 //   k_pack_gemm / k_copy / k_transpose   weight re-packing into MFMA fragment order (once per weight load)
-//   k_cond        time MLP + step embedding + all AdaLN (1+scale, shift) rows          decoder.py:77-80, transformer.py:64-66
+//   k_cond_mlp/_ada  time MLP + step embedding; all AdaLN (1+scale, shift) rows         decoder.py:77-80, transformer.py:64-66
 //   k_ctx         context embedding + per-layer low-rank cross K / V^T cache           decoder.py:83-93, mla.py:143-153
 //   k_prologue    in_proj + positional table, AdaRMSNorm(layer 0), QKV(layer 0)        decoder.py:96-97, attention.py:91-93
 //   k_layer<TAIL> one DiffusionTransformerBlock for a 32-frame wave tile, fully in registers:
@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdarg.h>
+#include <stdlib.h>
 #include <stdio.h>
 #include <string.h>
 
@@ -45,6 +46,24 @@ static int fail(int code, const char* fmt, ...) {
   do {                                                                                                  \
     hipError_t e_ = hipGetLastError();                                                                  \
     if (e_ != hipSuccess) return fail(EDTTS_ERR_HIP, "launch of %s failed: %s", name, hipGetErrorString(e_)); \
+  } while (0)
+
+// =========================================================================================================
+// optional per-launch timing of the dominant kernel (bench.py roofline leg)
+// =========================================================================================================
+#include <vector>
+struct Profiler {
+  std::vector<hipEvent_t> start, stop;
+  int used = 0;
+  bool on() const { return !start.empty(); }
+};
+static Profiler g_prof;
+#define PROF_LAUNCH(stream, launch_stmt)                                        \
+  do {                                                                          \
+    const bool rec_ = g_prof.on() && g_prof.used < (int)g_prof.start.size();    \
+    if (rec_) (void)hipEventRecord(g_prof.start[g_prof.used], (stream));         \
+    launch_stmt;                                                                \
+    if (rec_) (void)hipEventRecord(g_prof.stop[g_prof.used++], (stream));        \
   } while (0)
 
 // =========================================================================================================
@@ -214,13 +233,14 @@ struct CondArgs {
   const float *freqs, *t1T, *t1b, *t3T, *t3b, *step;
   const float* blob;
   unsigned ada1T[kMaxLayers], ada1b[kMaxLayers], ada3T[kMaxLayers], ada3b[kMaxLayers];  // offsets (floats) -- blob < 16 GiB
-  float* cond;  // [rows][L][2][2H]
+  float* cond;   // [rows][L][2][2H]
+  float* tcond;  // [rows][H] scratch
 };
-__global__ __launch_bounds__(256) void k_cond(CondArgs a) {
+// stage 1: t_cond row = Linear(GELU(Linear(sinus(t)))) + step_emb[step_idx]      (one block per row)
+__global__ __launch_bounds__(256) void k_cond_mlp(CondArgs a) {
   extern __shared__ float sm[];
-  float* e = sm;            // [H] sinusoidal embedding
-  float* u = sm + a.H;      // [H] hidden of the MLP
-  float* c = sm + 2 * a.H;  // [H] t_cond
+  float* e = sm;        // [H] sinusoidal embedding
+  float* u = sm + a.H;  // [H] hidden of the MLP
   const int row = blockIdx.x, tid = threadIdx.x, H = a.H, half = H / 2;
   const float tf = a.use_host ? (float)a.t_host[row] : (float)a.t[row];
   for (int j = tid; j < H; j += blockDim.x) {
@@ -230,6 +250,7 @@ __global__ __launch_bounds__(256) void k_cond(CondArgs a) {
   __syncthreads();
   for (int n = tid; n < H; n += blockDim.x) {
     float acc = a.t1b[n];
+#pragma unroll 8
     for (int k = 0; k < H; ++k) acc = fmaf(e[k], a.t1T[(size_t)k * H + n], acc);
     u[n] = 0.5f * acc * (1.0f + erff(acc * 0.70710678118654752440f));  // exact GELU (decoder.py:29)
   }
@@ -241,22 +262,26 @@ __global__ __launch_bounds__(256) void k_cond(CondArgs a) {
   }
   for (int n = tid; n < H; n += blockDim.x) {
     float acc = a.t3b[n];
+#pragma unroll 8
     for (int k = 0; k < H; ++k) acc = fmaf(u[k], a.t3T[(size_t)k * H + n], acc);
     if (sidx >= 0) acc += a.step[(size_t)sidx * H + n];
-    c[n] = acc;
+    a.tcond[(size_t)row * H + n] = acc;
   }
+}
+// stage 2: AdaLN rows (1 + scale | shift) = proj(t_cond) for every (row, layer, norm1|norm3)   (transformer.py:64-66)
+__global__ __launch_bounds__(256) void k_cond_ada(CondArgs a) {
+  extern __shared__ float sm[];
+  const int row = blockIdx.x, lw = blockIdx.y, l = lw >> 1, which = lw & 1, H = a.H;
+  for (int k = threadIdx.x; k < H; k += blockDim.x) sm[k] = a.tcond[(size_t)row * H + k];
   __syncthreads();
-  for (int l = 0; l < a.L; ++l) {
-    for (int which = 0; which < 2; ++which) {
-      const float* WT = a.blob + (which ? a.ada3T[l] : a.ada1T[l]);
-      const float* bb = a.blob + (which ? a.ada3b[l] : a.ada1b[l]);
-      float* out = a.cond + (((size_t)row * a.L + l) * 2 + which) * 2 * H;
-      for (int n = tid; n < 2 * H; n += blockDim.x) {
-        float acc = bb[n];
-        for (int k = 0; k < H; ++k) acc = fmaf(c[k], WT[(size_t)k * 2 * H + n], acc);
-        out[n] = n < H ? 1.0f + acc : acc;  // first half = scale (stored as 1+scale), second = shift
-      }
-    }
+  const float* WT = a.blob + (which ? a.ada3T[l] : a.ada1T[l]);
+  const float* bb = a.blob + (which ? a.ada3b[l] : a.ada1b[l]);
+  float* out = a.cond + (((size_t)row * a.L + l) * 2 + which) * 2 * H;
+  for (int n = blockIdx.z * blockDim.x + threadIdx.x; n < 2 * H; n += gridDim.z * blockDim.x) {
+    float acc = bb[n];
+#pragma unroll 8
+    for (int k = 0; k < H; ++k) acc = fmaf(sm[k], WT[(size_t)k * 2 * H + n], acc);
+    out[n] = n < H ? 1.0f + acc : acc;  // first half = scale (stored as 1+scale), second = shift
   }
 }
 
@@ -274,6 +299,7 @@ struct KArgs {
   const float* cond;  // row base: [L][2][2H] per row
   int cond_bstride;   // floats between batch rows (0 = one row shared by the batch)
   int layer;
+  int diag_skip;  // EDTTS_DIAG builds only: bit0 self-attn, bit1 q_proj+cross-attn, bit2 ffn, bit3 tail
   // weights
   const float *tok, *semp, *semp_b, *cpe, *inp, *inp_b, *pe;
   const float *n1w, *proj_b, *n2w, *n3w, *up_b, *down_b, *fnw, *fnb, *outp_b;
@@ -432,14 +458,19 @@ __global__ __launch_bounds__(kBlockThreads) void k_layer(KArgs a) {
       h[nt][1] = ldg4(hp + 16 * nt + 16 * C::H) + pb;
     }
   }
+#ifdef EDTTS_DIAG
+#define DIAG_ON(bit) (!(a.diag_skip & (bit)))
+#else
+#define DIAG_ON(bit) true
+#endif
   // ---- x = x + attn(norm1(x, cond))   (transformer.py:142-146; q/k/v were produced by the previous kernel) ----
-  {
+  if (DIAG_ON(1)) {
     QGlobal ql{a.q + rowbase * C::H, C::H};
     attention_fused<C, true>(ql, a.k + (size_t)b * a.Tp * C::H, a.vT + (size_t)b * C::VR * a.Tp, a.Tp, a.T, a.window, m0,
                              lane, ring, h);
   }
   // ---- x = x + cross_attn(norm2(x), context)   (transformer.py:151, mla.py:118-194) --------------------------
-  {
+  if (DIAG_ON(2)) {
     f4 hn[C::HT][2];
     rms_norm_tile<C::HT>(h, a.n2w, nullptr, g, hn);
     for (int nt = 0; nt < C::HT; ++nt) {
@@ -449,13 +480,13 @@ __global__ __launch_bounds__(kBlockThreads) void k_layer(KArgs a) {
       stg4(qtile + (16 + fq) * C::QLD + 16 * nt + 4 * g, a1);
     }
   }
-  {
+  if (DIAG_ON(2)) {
     QLds ql{qtile + fq * C::QLD, C::QLD};
     attention_fused<C, false>(ql, a.kc + (size_t)b * a.Sp * C::H, a.vcT + (size_t)b * C::VR * a.Sp, a.Sp, a.S, -1, m0, lane,
                               ring, h);
   }
   // ---- x = x + ffn(norm3(x, cond))   (transformer.py:154-158, :13-49) ----------------------------------------
-  {
+  if (DIAG_ON(4)) {
     f4 hn[C::HT][2];
     const float* mod = a.cond + (size_t)b * a.cond_bstride + ((size_t)a.layer * 2 + 1) * 2 * C::H;
     rms_norm_tile<C::HT>(h, a.n3w, mod, g, hn);
@@ -480,6 +511,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_layer(KArgs a) {
     }
   }
   // ---- tail ---------------------------------------------------------------------------------------------------
+  if (!DIAG_ON(8)) return;
   if (TAIL == TAIL_QKV) {
     float* hp = a.h + rowbase * C::H + 4 * g;
 #pragma unroll
@@ -778,7 +810,7 @@ static void make_workspace(const Layout& lo, int B, int T, int S, int cond_rows,
   w->vT = take((size_t)B * w->VR * w->Tp);
   w->kc = take((size_t)lo.L * B * w->Sp * H);
   w->vcT = take((size_t)lo.L * B * w->VR * w->Sp);
-  w->cond = take((size_t)cond_rows * lo.L * 2 * 2 * H);
+  w->cond = take((size_t)cond_rows * lo.L * 2 * 2 * H + (size_t)cond_rows * H);  // AdaLN rows + t_cond scratch
   w->total = o;
 }
 
@@ -811,6 +843,10 @@ struct Launcher {
     a->h = wsb + ws.h; a->q = wsb + ws.q; a->k = wsb + ws.k; a->vT = wsb + ws.vT;
     a->inp = blob + lo.inp; a->inp_b = blob + lo.inp_b; a->pe = blob + lo.pe;
     a->fnw = blob + lo.fnw; a->fnb = blob + lo.fnb; a->outp_b = blob + lo.outp_b;
+#ifdef EDTTS_DIAG
+    const char* e = getenv("EDTTS_DIAG_SKIP");
+    a->diag_skip = e ? atoi(e) : 0;
+#endif
   }
 
   // one decoder forward given conditioning rows + context cache already in the workspace
@@ -833,14 +869,14 @@ struct Launcher {
       a.vcT = wsb + ws.vcT + (size_t)l * B * ws.VR * ws.Sp;
       if (l + 1 < lo.L) {
         a.n1w = blob + lo.layer[l + 1].n1w;
-        hipLaunchKernelGGL((k_layer<C, TAIL_QKV>), dim3(g), dim3(kBlockThreads), layer_lds(), st, a);
+        PROF_LAUNCH(st, hipLaunchKernelGGL((k_layer<C, TAIL_QKV>), dim3(g), dim3(kBlockThreads), layer_lds(), st, a));
       } else if (tail == TAIL_EPS) {
         a.eps = eps;
-        hipLaunchKernelGGL((k_layer<C, TAIL_EPS>), dim3(g), dim3(kBlockThreads), layer_lds(), st, a);
+        PROF_LAUNCH(st, hipLaunchKernelGGL((k_layer<C, TAIL_EPS>), dim3(g), dim3(kBlockThreads), layer_lds(), st, a));
       } else {
         a.x_prev = x_prev; a.x0 = x0;
         a.c_s1m = coef[0]; a.c_sab = coef[1]; a.c_sabp = coef[2]; a.c_dir = coef[3];
-        hipLaunchKernelGGL((k_layer<C, TAIL_DDIM>), dim3(g), dim3(kBlockThreads), layer_lds(), st, a);
+        PROF_LAUNCH(st, hipLaunchKernelGGL((k_layer<C, TAIL_DDIM>), dim3(g), dim3(kBlockThreads), layer_lds(), st, a));
       }
       LAUNCH_CHECK("k_layer");
     }
@@ -888,8 +924,11 @@ static int launch_cond(const Layout& lo, const float* blob, const int64_t* t, co
     a.ada3T[l] = (unsigned)lo.layer[l].ada3T; a.ada3b[l] = (unsigned)lo.layer[l].ada3b;
   }
   a.cond = cond;
-  hipLaunchKernelGGL(k_cond, dim3(rows), dim3(256), 3 * lo.H * sizeof(float), st, a);
-  LAUNCH_CHECK("k_cond");
+  a.tcond = cond + (size_t)rows * lo.L * 2 * 2 * lo.H;  // scratch right behind the rows (see make_workspace)
+  hipLaunchKernelGGL(k_cond_mlp, dim3(rows), dim3(256), 2 * lo.H * sizeof(float), st, a);
+  LAUNCH_CHECK("k_cond_mlp");
+  hipLaunchKernelGGL(k_cond_ada, dim3(rows, 2 * lo.L, (2 * lo.H + 255) / 256), dim3(256), lo.H * sizeof(float), st, a);
+  LAUNCH_CHECK("k_cond_ada");
   return EDTTS_OK;
 }
 
@@ -1116,6 +1155,35 @@ int edtts_dsconv_forward(const float* x, const float* dw, const float* pw, const
   hipLaunchKernelGGL(k_dsconv_norm, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, z, stats, gn_w, gn_b, C_out, T, groups,
                      total, y);
   LAUNCH_CHECK("k_dsconv_norm");
+  return EDTTS_OK;
+}
+
+int edtts_profile_enable(int max_records) {
+  for (hipEvent_t e : g_prof.start) (void)hipEventDestroy(e);
+  for (hipEvent_t e : g_prof.stop) (void)hipEventDestroy(e);
+  g_prof.start.clear(); g_prof.stop.clear(); g_prof.used = 0;
+  if (max_records < 0) return fail(EDTTS_ERR_ARG, "max_records < 0");
+  for (int i = 0; i < max_records; ++i) {
+    hipEvent_t a, b;
+    HIP_TRY(hipEventCreate(&a));
+    HIP_TRY(hipEventCreate(&b));
+    g_prof.start.push_back(a); g_prof.stop.push_back(b);
+  }
+  return EDTTS_OK;
+}
+
+int edtts_profile_collect(double* layer_ms_total, int* layer_launches) {
+  if (!layer_ms_total || !layer_launches) return fail(EDTTS_ERR_ARG, "NULL pointer argument");
+  double tot = 0.0;
+  for (int i = 0; i < g_prof.used; ++i) {
+    HIP_TRY(hipEventSynchronize(g_prof.stop[i]));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, g_prof.start[i], g_prof.stop[i]));
+    tot += ms;
+  }
+  *layer_ms_total = tot;
+  *layer_launches = g_prof.used;
+  g_prof.used = 0;
   return EDTTS_OK;
 }
 

@@ -18,7 +18,8 @@ LIB_PATH = os.environ.get("EDTTS_LIB", os.path.join(os.path.dirname(_PKG_DIR), "
 EXPORTED_SYMBOLS = (
     "edtts_version", "edtts_last_error", "edtts_num_global_slots", "edtts_num_layer_slots", "edtts_global_slot_name",
     "edtts_layer_slot_name", "edtts_packed_bytes", "edtts_pack_weights", "edtts_workspace_bytes", "edtts_decoder_forward",
-    "edtts_ddim_step", "edtts_ddpm_step", "edtts_generate", "edtts_dsconv_forward",
+    "edtts_ddim_step", "edtts_ddpm_step", "edtts_generate", "edtts_dsconv_forward", "edtts_profile_enable",
+    "edtts_profile_collect",
 )
 
 
@@ -63,6 +64,8 @@ def lib() -> C.CDLL:
     L.edtts_generate.argtypes = [C.POINTER(EdttsDims), vp, vp, i32, i32, vp, vp, i32, C.POINTER(C.c_int64),
                                  C.POINTER(f32), vp, vp, vp]
     L.edtts_dsconv_forward.argtypes = [vp] * 6 + [i32] * 6 + [vp, vp, vp]
+    L.edtts_profile_enable.argtypes = [i32]
+    L.edtts_profile_collect.argtypes = [C.POINTER(C.c_double), C.POINTER(i32)]
     for name in EXPORTED_SYMBOLS:
         fn = getattr(L, name)
         if fn.restype is C.c_int and name not in ("edtts_version", "edtts_num_global_slots", "edtts_num_layer_slots"):
@@ -184,3 +187,14 @@ def dsconv_forward(x, dw, pw, pb, gn_w, gn_b, groups: int) -> torch.Tensor:
                                _dev_ptr(pb, f, "pointwise.bias"), _dev_ptr(gn_w, f, "norm.weight"), _dev_ptr(gn_b, f, "norm.bias"),
                                B, Ci, Co, T, ks, groups, scratch.data_ptr(), y.data_ptr(), _stream(x.device))
     return y
+
+
+def profile_enable(max_records: int) -> None:
+    lib().edtts_profile_enable(int(max_records))
+
+
+def profile_collect() -> Tuple[float, int]:
+    """(summed device ms of the transformer-layer kernel launches recorded since the last call, launch count)."""
+    ms, n = C.c_double(0.0), C.c_int(0)
+    lib().edtts_profile_collect(C.byref(ms), C.byref(n))
+    return ms.value, n.value

@@ -124,6 +124,14 @@ int edtts_dsconv_forward(const float* x, const float* dw, const float* pw, const
                          const float* gn_b, int B, int C_in, int C_out, int T, int ksize, int groups,
                          float* scratch, float* y, void* stream);
 
+/* ---- measurement hook (bench.py roofline leg) -----------------------------------------------------------
+ * edtts_profile_enable(n > 0): from now on every transformer-layer kernel launch (k_layer, the dominant kernel)
+ * is bracketed by a pair of hipEvents recorded on the stream it is launched on, up to n launches; n = 0
+ * disables and releases the events.  edtts_profile_collect synchronises on the recorded events, returns the
+ * summed device time (ms) and the number of launches, and resets the counter.  Not graph-capturable while on. */
+int edtts_profile_enable(int max_records);
+int edtts_profile_collect(double* layer_ms_total, int* layer_launches);
+
 #ifdef __cplusplus
 }
 #endif
