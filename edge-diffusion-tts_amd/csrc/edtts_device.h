@@ -25,9 +25,7 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 namespace edtts {
 
 constexpr int kWaveFrames = 32;  // frames per wave
-constexpr int kWavesPerBlock = 4;
-constexpr int kBlockThreads = 64 * kWavesPerBlock;
-constexpr int kBlockFrames = kWaveFrames * kWavesPerBlock;  // 128
+constexpr int kCtxWaves = 4;     // waves per block of the context kernel (no block-level sharing there)
 
 template <int H_, int HEADS_, int MEL_>
 struct Cfg {
@@ -42,6 +40,8 @@ struct Cfg {
   static constexpr int R = H / 2, RT = R / 16;    // kv_lora_rank (transformer.py:113) and its tiles
   static constexpr int VR = (HEADS - 1) * DH + DHP;  // rows of a V^T buffer (last head padded)
   static constexpr int QLD = H + 4;               // LDS row stride (floats) of the cross-attention q tile
+  static constexpr int WAVES = H > 192 ? 2 : 4;   // waves per block: bounded by LDS (weight ring + one q tile per wave)
+  static constexpr int THREADS = 64 * WAVES;
   static_assert(H % 32 == 0 && MEL % 16 == 0 && H % HEADS == 0, "dims");
   static_assert(DREM == 0 || DREM == 8, "head_dim % 16 must be 0 or 8");
 };
@@ -80,60 +80,102 @@ EDTTS_DEV float hsum(f4 v) { return (v[0] + v[1]) + (v[2] + v[3]); }
 EDTTS_DEV float hmax(f4 v) { return fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])); }
 
 // ---------------------------------------------------------------------------------------------------------
-// Weight fragment stream.  The packed weights of a kernel are laid out in CONSUMPTION order; every phase
-// (one n-tile of an n-major GEMM, or one k-tile of a k-major accumulate) consumes exactly N fragments.
-// The ring holds the next N fragments; using ring[i] immediately re-issues the load for fragment i of the
-// following phase, so the prefetch distance is one whole phase (N float4 loads = N KiB per wave in flight).
+// Weight fragment stream.  The packed weights of a kernel are laid out in CONSUMPTION order as one linear stream of
+// 1-KiB fragments.  FragRing<RN> keeps the next RN fragments in registers: position i of the current phase lives in
+// slot i % RN, and once the MFMAs that read a slot have been ISSUED the slot is refilled with stream element i + RN
+// (prefetch distance RN fragments = 8*RN MFMAs; RN must divide every phase length).  Refilling after use matters:
+// loading into the slot before its old value is consumed makes hipcc copy the whole ring and wait for every load at
+// the top of each phase (measured 126 -> 137 TFLOP/s on the bare stream).  The sched_barrier pins the issue point:
+// without it the pre-RA scheduler sinks each load to its use RN fragments later, i.e. load -> s_waitcnt -> MFMA.
 // ---------------------------------------------------------------------------------------------------------
-template <int N>
+template <int RN>
 struct FragRing {
-  const f4* p;  // lane-offset pointer to the ring's first fragment
-  f4 r[N];
+  const f4* p;  // lane-offset pointer to position 0 of the current phase
+  f4 r[RN];
   EDTTS_DEV void prime(const float* base, int lane) {
     p = reinterpret_cast<const f4*>(base) + lane;
 #pragma unroll
-    for (int i = 0; i < N; ++i) r[i] = p[i * 64];
+    for (int i = 0; i < RN; ++i) r[i] = p[i * 64];
   }
-  // take fragment i of the current phase and prefetch fragment i of the next one
-  EDTTS_DEV f4 take(int i) {
-    f4 a = r[i];
-    r[i] = p[(N + i) * 64];
-    // hipcc's pre-RA scheduler otherwise sinks this load down to its use one phase later (register-pressure
-    // heuristic), turning the prefetch into a load->wait->MFMA sequence; pin the issue point.
+  EDTTS_DEV const f4& at(int i) const { return r[i % RN]; }
+  EDTTS_DEV void refill(int i) {
+    r[i % RN] = p[(i + RN) * 64];
     __builtin_amdgcn_sched_barrier(0);
-    return a;
   }
-  EDTTS_DEV void advance() { p += N * 64; }
+  EDTTS_DEV void advance(int n) { p += n * 64; }
 };
 
-// out^T tile (16 features x 32 frames) = sum_kt frag(kt) * in[kt]:  one n-major phase (N = KT fragments).
-template <int KT>
-EDTTS_DEV void gemm_phase(FragRing<KT>& ring, const f4 (&in)[KT][2], f4& acc0, f4& acc1) {
+// out^T tile (16 features x 32 frames) += sum_kt frag(kt) * in[kt]: one n-major phase of KT fragments.  Even / odd k-tiles
+// go to separate accumulators (4 independent MFMA chains per wave: v_mfma_f32_16x16x4_f32 has a 40-cycle dependent
+// latency at a 32-cycle issue interval) and are summed at the end, which also halves each fp32 summation chain.
+template <int KT, int RN>
+EDTTS_DEV void gemm_phase(FragRing<RN>& ring, const f4 (&in)[KT][2], f4& acc0, f4& acc1) {
+  static_assert(KT % RN == 0, "phase length must be a multiple of the ring size");
+  f4 b0 = splat(0.f), b1 = splat(0.f);
 #pragma unroll
   for (int kt = 0; kt < KT; ++kt) {
-    f4 a = ring.take(kt);
+    const f4& a = ring.at(kt);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      acc0 = EDTTS_MFMA(a[r], in[kt][0][r], acc0);
-      acc1 = EDTTS_MFMA(a[r], in[kt][1][r], acc1);
+      if (kt & 1) {
+        b0 = EDTTS_MFMA(a[r], in[kt][0][r], b0);
+        b1 = EDTTS_MFMA(a[r], in[kt][1][r], b1);
+      } else {
+        acc0 = EDTTS_MFMA(a[r], in[kt][0][r], acc0);
+        acc1 = EDTTS_MFMA(a[r], in[kt][1][r], acc1);
+      }
     }
+    ring.refill(kt);
   }
-  ring.advance();
+  acc0 += b0;
+  acc1 += b1;
+  ring.advance(KT);
 }
 
-// acc[nt] += frag(nt) * in   for one k-tile of a k-major packed matrix (N = NT fragments).
-template <int NT>
-EDTTS_DEV void ktile_phase(FragRing<NT>& ring, f4 in0, f4 in1, f4 (&acc)[NT][2]) {
+// Two n-tiles at once from a stream that interleaves their fragments per k-tile ([kt][tile a | tile b]): the four
+// accumulators are the four independent chains.  Used for the FFN value/gate pair (layers/transformer.py:21-23).
+template <int KT, int RN>
+EDTTS_DEV void gemm_phase_pair(FragRing<RN>& ring, const f4 (&in)[KT][2], f4& a0, f4& a1, f4& b0, f4& b1) {
+  static_assert((2 * KT) % RN == 0, "phase length must be a multiple of the ring size");
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    f4 a = ring.take(nt);
+  for (int kt = 0; kt < KT; ++kt) {
+    const f4& fa = ring.at(2 * kt);
+    const f4& fb = ring.at(2 * kt + 1);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      acc[nt][0] = EDTTS_MFMA(a[r], in0[r], acc[nt][0]);
-      acc[nt][1] = EDTTS_MFMA(a[r], in1[r], acc[nt][1]);
+      a0 = EDTTS_MFMA(fa[r], in[kt][0][r], a0);
+      a1 = EDTTS_MFMA(fa[r], in[kt][1][r], a1);
+      b0 = EDTTS_MFMA(fb[r], in[kt][0][r], b0);
+      b1 = EDTTS_MFMA(fb[r], in[kt][1][r], b1);
     }
+    ring.refill(2 * kt);
+    ring.refill(2 * kt + 1);
   }
-  ring.advance();
+  ring.advance(2 * KT);
+}
+
+// acc[nt] += frag(nt) * in   for one k-tile of a k-major packed matrix (NT fragments); two n-tiles are interleaved so
+// that four accumulator chains are in flight.
+template <int NT, int RN>
+EDTTS_DEV void ktile_phase(FragRing<RN>& ring, f4 in0, f4 in1, f4 (&acc)[NT][2]) {
+  static_assert(NT % RN == 0, "phase length must be a multiple of the ring size");
+#pragma unroll
+  for (int nt = 0; nt < NT; nt += 2) {
+    const f4& fa = ring.at(nt);
+    const f4& fb = ring.at(nt + 1 < NT ? nt + 1 : nt);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      acc[nt][0] = EDTTS_MFMA(fa[r], in0[r], acc[nt][0]);
+      acc[nt][1] = EDTTS_MFMA(fa[r], in1[r], acc[nt][1]);
+      if (nt + 1 < NT) {
+        acc[nt + 1][0] = EDTTS_MFMA(fb[r], in0[r], acc[nt + 1][0]);
+        acc[nt + 1][1] = EDTTS_MFMA(fb[r], in1[r], acc[nt + 1][1]);
+      }
+    }
+    ring.refill(nt);
+    if (nt + 1 < NT) ring.refill(nt + 1);
+  }
+  ring.advance(NT);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -209,6 +251,15 @@ EDTTS_DEV float silu(float g) { return g / (1.0f + __expf(-g)); }
 //   SELF : keys are frames of the same utterance, band |i-j| <= window (layers/attention.py:27-30,108-112)
 //   !SELF: keys are the S context tokens, no mask (layers/mla.py:158-179)
 // ---------------------------------------------------------------------------------------------------------
+// weight stream of the layer / prologue kernels: a per-wave register ring of HT/2 fragments straight from L2.
+// (A block-shared LDS ring -- each fragment fetched once per block, ds_read_b128 to the MFMA -- was built and measured:
+// 6 % slower at B=256, T=512, because its per-phase block barrier costs more than the 4x L2 traffic it saves; see
+// DESIGN.md "What was tried".)
+#ifndef EDTTS_RING_DIV
+#define EDTTS_RING_DIV 1
+#endif
+template <class C> using WStream = FragRing<(C::HT / EDTTS_RING_DIV >= 2 ? C::HT / EDTTS_RING_DIV : 2)>;
+
 constexpr int kChunk = 2;  // key tiles (16 keys each) per online-softmax step
 
 template <class C>
@@ -219,7 +270,7 @@ struct KVFrag {  // MFMA A operands of one chunk of key tiles, for one head
 
 template <class C, bool SELF, class QLoad>
 EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, const float* __restrict__ VTb, int ldv,
-                               int nkeys, int window, int m0, int lane, FragRing<C::HT>& ring, f4 (&h)[C::HT][2]) {
+                               int nkeys, int window, int m0, int lane, WStream<C>& ring, f4 (&h)[C::HT][2]) {
   constexpr int DH = C::DH, DFULL = C::DFULL, DREM = C::DREM, DT = C::DT, H = C::H, CH = kChunk;
   const int fq = lane & 15, g = lane >> 4;
   // softmax in base 2: p = 2^((s - m) * c), c = log2(e) / sqrt(d)
@@ -288,17 +339,28 @@ EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, cons
     }
   };
 
+  // chunk c holds keys [k0, k0+16*CH).  It needs no masking at all when every key is inside the band of every query of the
+  // wave and below klim (3 of the 5 chunks at window 64, every chunk of the cross-attention when S % 32 == 0)
+  auto chunk_full = [&](int c) {
+    const int k0 = (kt_lo + c * CH) << 4, k1 = k0 + 16 * CH - 1;
+    bool full = k1 < klim && (kt_lo + (c + 1) * CH) <= kt_hi;
+    if (SELF && window >= 0) full = full && (k1 - m0 <= window) && (k0 - (m0 + kWaveFrames - 1) >= -window);
+    return full;
+  };
+
   for (int hd = 0; hd < C::HEADS; ++hd) {
-    // ---- q fragments of this head (B operand): lane (fq,g) holds q[query][hd*DH + 16a + 4g + b] -------------
+    // ---- q fragments of this head (B operand): lane (fq,g) holds q[query][hd*DH + 16a + 4g + b], pre-scaled by
+    //      log2(e)/sqrt(d) so the scores come out of the MFMA in the exp2 domain -------------------------------------
     f4 qa[2][DFULL > 0 ? DFULL : 1];
     f2 qr[2];
 #pragma unroll
     for (int ft = 0; ft < 2; ++ft) {
 #pragma unroll
-      for (int a = 0; a < DFULL; ++a) qa[ft][a] = qload.q4(ft, hd * DH + 16 * a + 4 * g);
-      if (DREM) qr[ft] = qload.q2(ft, hd * DH + 16 * DFULL + 2 * g);
+      for (int a = 0; a < DFULL; ++a) qa[ft][a] = qload.q4(ft, hd * DH + 16 * a + 4 * g) * c2;
+      if (DREM) qr[ft] = qload.q2(ft, hd * DH + 16 * DFULL + 2 * g) * c2;
     }
-    float mrun[2] = {-1e30f, -1e30f}, lrun[2] = {0.f, 0.f};
+    float mrun[2] = {-1e30f, -1e30f};
+    f4 lvec[2] = {splat(0.f), splat(0.f)};  // per-lane partial row sums (reduced over r and the lane groups at the end)
     f4 O[DT][2];
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) O[dt][0] = O[dt][1] = splat(0.f);
@@ -323,37 +385,46 @@ EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, cons
       kcur = knext;
       load_k(hd, c + 2 < nchunk ? c + 2 : nchunk - 1, knext);
       __builtin_amdgcn_sched_barrier(0);
+      // ---- band / length mask of the current chunk (skipped, wave-uniformly, for interior chunks).  Done BEFORE the next
+      //      chunk's QK^T is issued so that those MFMAs and the softmax VALU below share one scheduling region ----------
+      if (!chunk_full(c)) {  // wave-uniform
+        const int k0 = (kt_lo + c * CH) << 4;
+#pragma unroll
+        for (int ft = 0; ft < 2; ++ft) {
+          const int d0 = k0 + 4 * g - (m0 + 16 * ft + fq) - lo_d[ft];  // (key - query - lo_d) of r = 0, tile 0
+          const unsigned sp = span[ft] >= 0 ? (unsigned)span[ft] : 0u;
+          const int bias = span[ft] >= 0 ? 0 : (1 << 30);               // nothing valid for this query
+#pragma unroll
+          for (int t = 0; t < CH; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              Scur[t][ft][r] = (unsigned)(d0 + bias + 16 * t + r) <= sp ? Scur[t][ft][r] : NEG_INF;
+        }
+      }
       // scores of the NEXT chunk: independent MFMA work the scheduler can overlap with this chunk's softmax VALU
       // (on the last chunk this recomputes a clamped chunk whose result is unused)
       qk(kcur, qa, qr, Snext);
       // ---- online softmax of the current chunk ----------------------------------------------------------------
-      const int k0 = (kt_lo + c * CH) << 4;
       f4 P[CH][2];
 #pragma unroll
       for (int ft = 0; ft < 2; ++ft) {
-        const int d0 = k0 + 4 * g - (m0 + 16 * ft + fq) - lo_d[ft];  // (key - query - lo_d) of r = 0, tile 0
-        float mx = NEG_INF;
+        f4 mv = Scur[0][ft];
 #pragma unroll
-        for (int t = 0; t < CH; ++t)
+        for (int t = 1; t < CH; ++t)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const bool ok = (unsigned)(d0 + 16 * t + r) <= (unsigned)span[ft] && span[ft] >= 0;
-            const float v = ok ? Scur[t][ft][r] * c2 : NEG_INF;
-            Scur[t][ft][r] = v;
-            mx = fmaxf(mx, v);
-          }
-        mx = group_max(mx);
+          for (int r = 0; r < 4; ++r) mv[r] = fmaxf(mv[r], Scur[t][ft][r]);
+        const float mx = group_max(hmax(mv));
         const float mnew = fmaxf(mrun[ft], mx);  // mrun starts at a finite -1e30, so exp2(-inf - mnew) = 0, never NaN
         const float alpha = fast_exp2(mrun[ft] - mnew);
         mrun[ft] = mnew;
-        float ps = 0.f;
+        f4 ps = splat(0.f);
 #pragma unroll
         for (int t = 0; t < CH; ++t) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) P[t][ft][r] = fast_exp2(Scur[t][ft][r] - mnew);
-          ps += hsum(P[t][ft]);
+          ps += P[t][ft];
         }
-        lrun[ft] = lrun[ft] * alpha + ps;
+        lvec[ft] = lvec[ft] * alpha + ps;
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) O[dt][ft] *= alpha;
       }
@@ -376,7 +447,7 @@ EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, cons
     // ---- normalise and project: h[nt] += Wo[:, head features] . O ------------------------------------------
 #pragma unroll
     for (int ft = 0; ft < 2; ++ft) {
-      const float lt = group_sum(lrun[ft]);
+      const float lt = group_sum(hsum(lvec[ft]));
       const float inv = lt > 0.f ? 1.0f / lt : 0.f;
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) O[dt][ft] *= inv;

@@ -144,7 +144,7 @@ static int make_layout(const EdttsDims* d, Layout* lo) {
     y.s_body = o; o += (KPT * HT /*proj*/ + HT * HT /*q_proj*/ + KPT * HT /*out_proj*/ + 2 * HT * 3 * HT /*ffn*/) * kFrag;
   }
   lo->s_outp = o; o += MT * HT * kFrag;
-  o += HT * kFrag;  // the ring prefetches one phase past the last consumed fragment
+  o += 4 * HT * kFrag;  // the stream stages two phases (+ slot padding) past the last consumed fragment
   lo->total = align64(o);
   return EDTTS_OK;
 }
@@ -193,7 +193,7 @@ __global__ void k_pack_gemm(PackArgs a) {
   switch (a.dstmode) {
     case 0: frag = (size_t)nt * a.KT + kt; break;
     case 1: frag = (size_t)kt * a.NT + nt; break;
-    case 2: frag = (size_t)(nt >> 1) * (3 * a.KT) + (nt & 1) * a.KT + kt; break;        // up: [j][val KT | gate KT | down NT]
+    case 2: frag = (size_t)(nt >> 1) * (3 * a.KT) + 2 * kt + (nt & 1); break;           // up: [j][kt][value | gate], then down NT
     default: frag = (size_t)kt * (3 * a.NT) + 2 * a.NT + nt; break;                       // down: k-tile kt = hidden tile j
   }
   (void)S3;
@@ -320,14 +320,16 @@ EDTTS_DEV int remap_block(int bid, int nblk) {
 
 struct TileId {
   int b, m0;
-  bool valid;
+  bool valid;  // false: a padding wave of the last block -- it recomputes the last tile (keeps the block's barriers
+               // balanced) and must not store anything
 };
-EDTTS_DEV TileId wave_tile(int B, int Tp) {
+EDTTS_DEV TileId wave_tile(int B, int Tp, int waves_per_block) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int tpu = Tp / kWaveFrames;
-  const int w = remap_block(blockIdx.x, gridDim.x) * kWavesPerBlock + wave;
+  int w = remap_block(blockIdx.x, gridDim.x) * waves_per_block + wave;
   TileId t;
   t.valid = w < B * tpu;
+  w = t.valid ? w : B * tpu - 1;
   t.b = w / tpu;
   t.m0 = (w - t.b * tpu) * kWaveFrames;
   return t;
@@ -338,13 +340,14 @@ EDTTS_DEV TileId wave_tile(int B, int Tp) {
 // (layers/attention.py:91-93: rows of qkv.weight are q | k | v, each head-major)
 // ---------------------------------------------------------------------------------------------------------
 template <class C>
-EDTTS_DEV void qkv_tail(FragRing<C::HT>& ring, const f4 (&hn)[C::HT][2], const KArgs& a, int b, int m0, int lane) {
+EDTTS_DEV void qkv_tail(WStream<C>& ring, const f4 (&hn)[C::HT][2], const KArgs& a, int b, int m0, int lane, bool valid) {
   const int fq = lane & 15, g = lane >> 4;
   const size_t rowbase = (size_t)b * a.Tp + m0 + fq;
   for (int which = 0; which < 3; ++which) {
     for (int nt = 0; nt < C::HT; ++nt) {
       f4 a0 = splat(0.f), a1 = splat(0.f);
       gemm_phase<C::HT>(ring, hn, a0, a1);
+      if (!valid) continue;
       if (which < 2) {
         float* dst = (which == 0 ? a.q : a.k) + rowbase * C::H + 16 * nt + 4 * g;
         stg4(dst, a0);
@@ -365,11 +368,14 @@ EDTTS_DEV void qkv_tail(FragRing<C::HT>& ring, const f4 (&hn)[C::HT][2], const K
 // prologue: h = in_proj(x) + pe ; AdaRMSNorm(layer 0) ; QKV(layer 0)
 // =========================================================================================================
 template <class C>
-__global__ __launch_bounds__(kBlockThreads) void k_prologue(KArgs a) {
-  const TileId tl = wave_tile(a.B, a.Tp);
-  if (!tl.valid) return;
+__global__ __launch_bounds__(C::THREADS) void k_prologue(KArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const TileId tl = wave_tile(a.B, a.Tp, C::WAVES);
   const int lane = threadIdx.x & 63, fq = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int b = tl.b, m0 = tl.m0;
+  WStream<C> ring;
+  ring.prime(a.stream, lane);
   f4 xin[C::MT][2];
 #pragma unroll
   for (int ft = 0; ft < 2; ++ft) {
@@ -399,9 +405,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_prologue(KArgs a) {
       }
     }
   }
-  FragRing<C::HT> ring;
-  ring.prime(a.stream, lane);
-  {
+  if (tl.valid) {
     float* hp = a.h + ((size_t)b * a.Tp + m0 + fq) * C::H + 4 * g;
 #pragma unroll
     for (int nt = 0; nt < C::HT; ++nt) {
@@ -412,7 +416,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_prologue(KArgs a) {
   f4 hn[C::HT][2];
   const float* mod = a.cond + (size_t)b * a.cond_bstride;  // layer 0, norm1
   rms_norm_tile<C::HT>(h, a.n1w, mod, g, hn);
-  qkv_tail<C>(ring, hn, a, b, m0, lane);
+  qkv_tail<C>(ring, hn, a, b, m0, lane, tl.valid);
 }
 
 // =========================================================================================================
@@ -434,17 +438,16 @@ struct QLds {  // q tile in this wave's LDS region, [32][QLD]
 };
 
 template <class C, int TAIL>
-__global__ __launch_bounds__(kBlockThreads) void k_layer(KArgs a) {
+__global__ __launch_bounds__(C::THREADS) void k_layer(KArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const TileId tl = wave_tile(a.B, a.Tp);
-  if (!tl.valid) return;
+  const TileId tl = wave_tile(a.B, a.Tp, C::WAVES);
   const int lane = threadIdx.x & 63, fq = lane & 15, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int b = tl.b, m0 = tl.m0;
   float* qtile = smem + (size_t)wave * kWaveFrames * C::QLD;
   const size_t rowbase = (size_t)b * a.Tp + m0 + fq;
 
-  FragRing<C::HT> ring;
+  WStream<C> ring;
   ring.prime(a.stream, lane);
 
   // residual stream tile, + self-attention projection bias (attention.py:123)
@@ -499,8 +502,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_layer(KArgs a) {
     for (int j = 0; j < 2 * C::HT; ++j) {
       const f4 vb = ldg4(a.up_b + 32 * j + 4 * g), gb = ldg4(a.up_b + 32 * j + 16 + 4 * g);
       f4 v0 = vb, v1 = vb, g0 = gb, g1 = gb;
-      gemm_phase<C::HT>(ring, hn, v0, v1);
-      gemm_phase<C::HT>(ring, hn, g0, g1);
+      gemm_phase_pair<C::HT>(ring, hn, v0, v1, g0, g1);
       f4 act0, act1;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -513,16 +515,18 @@ __global__ __launch_bounds__(kBlockThreads) void k_layer(KArgs a) {
   // ---- tail ---------------------------------------------------------------------------------------------------
   if (!DIAG_ON(8)) return;
   if (TAIL == TAIL_QKV) {
-    float* hp = a.h + rowbase * C::H + 4 * g;
+    if (tl.valid) {
+      float* hp = a.h + rowbase * C::H + 4 * g;
 #pragma unroll
-    for (int nt = 0; nt < C::HT; ++nt) {
-      stg4(hp + 16 * nt, h[nt][0]);
-      stg4(hp + 16 * nt + 16 * C::H, h[nt][1]);
+      for (int nt = 0; nt < C::HT; ++nt) {
+        stg4(hp + 16 * nt, h[nt][0]);
+        stg4(hp + 16 * nt + 16 * C::H, h[nt][1]);
+      }
     }
     f4 hn[C::HT][2];
     const float* mod = a.cond + (size_t)b * a.cond_bstride + ((size_t)(a.layer + 1) * 2) * 2 * C::H;
     rms_norm_tile<C::HT>(h, a.n1w, mod, g, hn);
-    qkv_tail<C>(ring, hn, a, b, m0, lane);
+    qkv_tail<C>(ring, hn, a, b, m0, lane, tl.valid);
   } else {
     f4 hn[C::HT][2];
     layer_norm_tile<C::HT>(h, a.fnw, a.fnb, g, hn);
@@ -534,7 +538,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_layer(KArgs a) {
 #pragma unroll
       for (int ft = 0; ft < 2; ++ft) {
         const int f = m0 + 16 * ft + fq;
-        if (f >= a.T) continue;
+        if (f >= a.T || !tl.valid) continue;
         const size_t idx = ((size_t)b * a.T + f) * C::MEL + 16 * nt + 4 * g;
         const f4 e = ft ? e1 : e0;
         if (TAIL == TAIL_EPS) {
@@ -571,9 +575,9 @@ struct CtxArgs {
   float *kc, *vcT;  // [L][B][Sp][H], [L][B][VR][Sp]
 };
 template <class C>
-__global__ __launch_bounds__(kBlockThreads) void k_ctx(CtxArgs a) {
-  const TileId tl = wave_tile(a.B, a.Sp);
-  if (!tl.valid) return;
+__global__ __launch_bounds__(64 * kCtxWaves) void k_ctx(CtxArgs a) {
+  const TileId tl = wave_tile(a.B, a.Sp, kCtxWaves);
+  if (!tl.valid) return;  // no block-level synchronisation in this kernel
   const int lane = threadIdx.x & 63, fq = lane & 15, g = lane >> 4;
   const int b = tl.b, m0 = tl.m0;
   f4 ctx[C::HT][2];
@@ -816,8 +820,10 @@ static void make_workspace(const Layout& lo, int B, int T, int S, int cond_rows,
 
 template <class C>
 struct Launcher {
-  static size_t layer_lds() { return (size_t)kWavesPerBlock * kWaveFrames * C::QLD * sizeof(float); }
-  static int grid(int B, int Tp) { return (B * (Tp / kWaveFrames) + kWavesPerBlock - 1) / kWavesPerBlock; }
+  static size_t ring_lds() { return 0; }
+  static size_t layer_lds() { return ring_lds() + (size_t)C::WAVES * kWaveFrames * C::QLD * sizeof(float); }
+  static int grid(int B, int Tp) { return (B * (Tp / kWaveFrames) + C::WAVES - 1) / C::WAVES; }
+  static int ctx_grid(int B, int Sp) { return (B * (Sp / kWaveFrames) + kCtxWaves - 1) / kCtxWaves; }
 
   static int ctx(const Layout& lo, const float* blob, const Workspace& ws, float* wsb, int B, int S, const int64_t* sem_idx,
                  const float* sem_feat, hipStream_t st) {
@@ -830,7 +836,7 @@ struct Launcher {
       a.kvd[l] = (unsigned)lo.layer[l].kvd; a.kvn[l] = (unsigned)lo.layer[l].kvn; a.kvu[l] = (unsigned)lo.layer[l].kvu;
     }
     a.kc = wsb + ws.kc; a.vcT = wsb + ws.vcT;
-    hipLaunchKernelGGL(k_ctx<C>, dim3(grid(B, ws.Sp)), dim3(kBlockThreads), 0, st, a);
+    hipLaunchKernelGGL(k_ctx<C>, dim3(ctx_grid(B, ws.Sp)), dim3(64 * kCtxWaves), 0, st, a);
     LAUNCH_CHECK("k_ctx");
     return EDTTS_OK;
   }
@@ -858,7 +864,7 @@ struct Launcher {
     a.x = x; a.cond = cond_row; a.cond_bstride = cond_bstride;
     const int g = grid(B, ws.Tp);
     a.n1w = blob + lo.layer[0].n1w; a.stream = blob + lo.layer[0].s_qkv; a.layer = 0;
-    hipLaunchKernelGGL(k_prologue<C>, dim3(g), dim3(kBlockThreads), 0, st, a);
+    hipLaunchKernelGGL(k_prologue<C>, dim3(g), dim3(C::THREADS), ring_lds(), st, a);
     LAUNCH_CHECK("k_prologue");
     for (int l = 0; l < lo.L; ++l) {
       const LayerLayout& y = lo.layer[l];
@@ -869,14 +875,14 @@ struct Launcher {
       a.vcT = wsb + ws.vcT + (size_t)l * B * ws.VR * ws.Sp;
       if (l + 1 < lo.L) {
         a.n1w = blob + lo.layer[l + 1].n1w;
-        PROF_LAUNCH(st, hipLaunchKernelGGL((k_layer<C, TAIL_QKV>), dim3(g), dim3(kBlockThreads), layer_lds(), st, a));
+        PROF_LAUNCH(st, hipLaunchKernelGGL((k_layer<C, TAIL_QKV>), dim3(g), dim3(C::THREADS), layer_lds(), st, a));
       } else if (tail == TAIL_EPS) {
         a.eps = eps;
-        PROF_LAUNCH(st, hipLaunchKernelGGL((k_layer<C, TAIL_EPS>), dim3(g), dim3(kBlockThreads), layer_lds(), st, a));
+        PROF_LAUNCH(st, hipLaunchKernelGGL((k_layer<C, TAIL_EPS>), dim3(g), dim3(C::THREADS), layer_lds(), st, a));
       } else {
         a.x_prev = x_prev; a.x0 = x0;
         a.c_s1m = coef[0]; a.c_sab = coef[1]; a.c_sabp = coef[2]; a.c_dir = coef[3];
-        PROF_LAUNCH(st, hipLaunchKernelGGL((k_layer<C, TAIL_DDIM>), dim3(g), dim3(kBlockThreads), layer_lds(), st, a));
+        PROF_LAUNCH(st, hipLaunchKernelGGL((k_layer<C, TAIL_DDIM>), dim3(g), dim3(C::THREADS), layer_lds(), st, a));
       }
       LAUNCH_CHECK("k_layer");
     }
