@@ -305,6 +305,7 @@ EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, cons
 
   // loads of one chunk's K fragments (tile index clamped: tiles past kt_hi are fully masked by klim)
   auto load_k = [&](int hd, int c, KVFrag<C>& f) {
+    c = c < nchunk ? c : nchunk - 1;
 #pragma unroll
     for (int t = 0; t < CH; ++t) {
       int kt = kt_lo + c * CH + t;
@@ -315,10 +316,32 @@ EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, cons
       if (DREM) f.kr[t] = ldg2(kp + 16 * DFULL + 2 * g);
     }
   };
-  // S^T chunk = K Q^T for both query tiles, accumulators interleaved (ft 0/1 alternate -> no dependent back-to-back MFMAs)
-  auto qk = [&](const KVFrag<C>& f, const f4 (&qa)[2][DFULL > 0 ? DFULL : 1], const f2 (&qr)[2], f4 (&S)[CH][2]) {
+  // Mask of chunk c as the INITIAL accumulator of its K Q^T product: 0 where the key is visible, -inf elsewhere
+  // (-inf + finite products = -inf).  Computed before the MFMAs are issued, so no VALU work sits between the MFMA
+  // results and the softmax; interior chunks (every key inside the band of every query of the wave and below klim: 3 of
+  // the 5 chunks at window 64, all of the cross-attention when S % 32 == 0) take the wave-uniform zero path.
+  auto mask_init = [&](int c, f4 (&S)[CH][2]) {
+    c = c < nchunk ? c : nchunk - 1;
+    const int k0 = (kt_lo + c * CH) << 4, k1 = k0 + 16 * CH - 1;
+    bool full = k1 < klim && (kt_lo + (c + 1) * CH) <= kt_hi;
+    if (SELF && window >= 0) full = full && (k1 - m0 <= window) && (k0 - (m0 + kWaveFrames - 1) >= -window);
 #pragma unroll
     for (int t = 0; t < CH; ++t) S[t][0] = S[t][1] = splat(0.f);
+    if (!full) {
+#pragma unroll
+      for (int ft = 0; ft < 2; ++ft) {
+        const int d0 = k0 + 4 * g - (m0 + 16 * ft + fq) - lo_d[ft];  // (key - query - lo_d) of r = 0, tile 0
+        const unsigned sp = span[ft] >= 0 ? (unsigned)span[ft] : 0u;
+        const int bias = span[ft] >= 0 ? 0 : (1 << 30);               // nothing valid for this query
+#pragma unroll
+        for (int t = 0; t < CH; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) S[t][ft][r] = (unsigned)(d0 + bias + 16 * t + r) <= sp ? 0.f : NEG_INF;
+      }
+    }
+  };
+  // S^T chunk += K Q^T for both query tiles, accumulators interleaved (2*CH independent chains)
+  auto qk = [&](const KVFrag<C>& f, const f4 (&qa)[2][DFULL > 0 ? DFULL : 1], const f2 (&qr)[2], f4 (&S)[CH][2]) {
 #pragma unroll
     for (int a = 0; a < DFULL; ++a)
 #pragma unroll
@@ -339,15 +362,6 @@ EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, cons
     }
   };
 
-  // chunk c holds keys [k0, k0+16*CH).  It needs no masking at all when every key is inside the band of every query of the
-  // wave and below klim (3 of the 5 chunks at window 64, every chunk of the cross-attention when S % 32 == 0)
-  auto chunk_full = [&](int c) {
-    const int k0 = (kt_lo + c * CH) << 4, k1 = k0 + 16 * CH - 1;
-    bool full = k1 < klim && (kt_lo + (c + 1) * CH) <= kt_hi;
-    if (SELF && window >= 0) full = full && (k1 - m0 <= window) && (k0 - (m0 + kWaveFrames - 1) >= -window);
-    return full;
-  };
-
   for (int hd = 0; hd < C::HEADS; ++hd) {
     // ---- q fragments of this head (B operand): lane (fq,g) holds q[query][hd*DH + 16a + 4g + b], pre-scaled by
     //      log2(e)/sqrt(d) so the scores come out of the MFMA in the exp2 domain -------------------------------------
@@ -365,15 +379,11 @@ EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, cons
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) O[dt][0] = O[dt][1] = splat(0.f);
 
-    KVFrag<C> kcur, knext;
-    f4 Scur[CH][2], Snext[CH][2];
-    load_k(hd, 0, kcur);
-    load_k(hd, nchunk > 1 ? 1 : 0, knext);
-    __builtin_amdgcn_sched_barrier(0);
-    qk(kcur, qa, qr, Scur);
-
-    for (int c = 0; c < nchunk; ++c) {
-      // V^T fragments of this chunk (needed after the softmax) and K fragments two chunks ahead
+    // One step: finish chunk c (softmax + P V) while the scores of chunk c+1 are produced.
+    //   Sc   : scores of chunk c (complete)          Sn : receives the scores of chunk c+1 (its mask is already in it)
+    //   Kuse : K fragments of chunk c+1 (loaded one step ago)     Kld : receives the K fragments of chunk c+2
+    // The caller alternates the two S / K buffers, so nothing is copied between steps.
+    auto step = [&](int c, f4 (&Sc)[CH][2], f4 (&Sn)[CH][2], const KVFrag<C>& Kuse, KVFrag<C>& Kld) {
       f4 va[CH][DT];
 #pragma unroll
       for (int t = 0; t < CH; ++t) {
@@ -382,37 +392,19 @@ EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, cons
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) va[t][dt] = ldg4(VTb + (size_t)(hd * DH + 16 * dt + fq) * ldv + (kt << 4) + 4 * g);
       }
-      kcur = knext;
-      load_k(hd, c + 2 < nchunk ? c + 2 : nchunk - 1, knext);
+      load_k(hd, c + 2, Kld);
       __builtin_amdgcn_sched_barrier(0);
-      // ---- band / length mask of the current chunk (skipped, wave-uniformly, for interior chunks).  Done BEFORE the next
-      //      chunk's QK^T is issued so that those MFMAs and the softmax VALU below share one scheduling region ----------
-      if (!chunk_full(c)) {  // wave-uniform
-        const int k0 = (kt_lo + c * CH) << 4;
-#pragma unroll
-        for (int ft = 0; ft < 2; ++ft) {
-          const int d0 = k0 + 4 * g - (m0 + 16 * ft + fq) - lo_d[ft];  // (key - query - lo_d) of r = 0, tile 0
-          const unsigned sp = span[ft] >= 0 ? (unsigned)span[ft] : 0u;
-          const int bias = span[ft] >= 0 ? 0 : (1 << 30);               // nothing valid for this query
-#pragma unroll
-          for (int t = 0; t < CH; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-              Scur[t][ft][r] = (unsigned)(d0 + bias + 16 * t + r) <= sp ? Scur[t][ft][r] : NEG_INF;
-        }
-      }
-      // scores of the NEXT chunk: independent MFMA work the scheduler can overlap with this chunk's softmax VALU
-      // (on the last chunk this recomputes a clamped chunk whose result is unused)
-      qk(kcur, qa, qr, Snext);
-      // ---- online softmax of the current chunk ----------------------------------------------------------------
+      // scores of the NEXT chunk: independent MFMA work that overlaps this chunk's softmax VALU (same scheduling region).
+      // On the last chunk this recomputes a clamped chunk whose result is unused.
+      qk(Kuse, qa, qr, Sn);
       f4 P[CH][2];
 #pragma unroll
       for (int ft = 0; ft < 2; ++ft) {
-        f4 mv = Scur[0][ft];
+        f4 mv = Sc[0][ft];
 #pragma unroll
         for (int t = 1; t < CH; ++t)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) mv[r] = fmaxf(mv[r], Scur[t][ft][r]);
+          for (int r = 0; r < 4; ++r) mv[r] = fmaxf(mv[r], Sc[t][ft][r]);
         const float mx = group_max(hmax(mv));
         const float mnew = fmaxf(mrun[ft], mx);  // mrun starts at a finite -1e30, so exp2(-inf - mnew) = 0, never NaN
         const float alpha = fast_exp2(mrun[ft] - mnew);
@@ -421,14 +413,14 @@ EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, cons
 #pragma unroll
         for (int t = 0; t < CH; ++t) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) P[t][ft][r] = fast_exp2(Scur[t][ft][r] - mnew);
+          for (int r = 0; r < 4; ++r) P[t][ft][r] = fast_exp2(Sc[t][ft][r] - mnew);
           ps += P[t][ft];
         }
         lvec[ft] = lvec[ft] * alpha + ps;
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) O[dt][ft] *= alpha;
       }
-      // ---- O^T += V^T P^T : DT x 2 independent accumulators, r outermost -------------------------------------------
+      // O^T += V^T P^T : DT x 2 independent accumulators, r outermost
 #pragma unroll
       for (int t = 0; t < CH; ++t)
 #pragma unroll
@@ -438,11 +430,25 @@ EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, cons
             O[dt][0] = EDTTS_MFMA(va[t][dt][r], P[t][0][r], O[dt][0]);
             O[dt][1] = EDTTS_MFMA(va[t][dt][r], P[t][1][r], O[dt][1]);
           }
-#pragma unroll
-      for (int t = 0; t < CH; ++t) {
-        Scur[t][0] = Snext[t][0];
-        Scur[t][1] = Snext[t][1];
-      }
+    };
+
+    KVFrag<C> KA, KB;
+    f4 SA[CH][2], SB[CH][2];
+    load_k(hd, 0, KA);
+    load_k(hd, 1, KB);
+    mask_init(0, SA);
+    __builtin_amdgcn_sched_barrier(0);
+    qk(KA, qa, qr, SA);  // scores of chunk 0; KB holds chunk 1
+    int c = 0;
+    for (; c + 1 < nchunk; c += 2) {
+      mask_init(c + 1, SB);
+      step(c, SA, SB, KB, KA);      // finishes chunk c,   scores of c+1 -> SB (from KB), loads K(c+2) -> KA
+      mask_init(c + 2, SA);
+      step(c + 1, SB, SA, KA, KB);  // finishes chunk c+1, scores of c+2 -> SA (from KA), loads K(c+3) -> KB
+    }
+    if (c < nchunk) {               // odd chunk count: last chunk's scores are in SA
+      mask_init(c + 1, SB);
+      step(c, SA, SB, KB, KA);
     }
     // ---- normalise and project: h[nt] += Wo[:, head features] . O ------------------------------------------
 #pragma unroll
