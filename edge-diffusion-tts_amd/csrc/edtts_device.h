@@ -15,6 +15,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef float f2 __attribute__((ext_vector_type(2)));
@@ -261,6 +262,7 @@ EDTTS_DEV float silu(float g) { return g / (1.0f + __expf(-g)); }
 template <class C> using WStream = FragRing<(C::HT / EDTTS_RING_DIV >= 2 ? C::HT / EDTTS_RING_DIV : 2)>;
 
 constexpr int kChunk = 2;  // key tiles (16 keys each) per online-softmax step
+constexpr float kDefer = 32.f;  // octaves a chunk may exceed the softmax reference point before it is moved
 
 template <class C>
 struct KVFrag {  // MFMA A operands of one chunk of key tiles, for one head
@@ -383,7 +385,7 @@ EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, cons
     //   Sc   : scores of chunk c (complete)          Sn : receives the scores of chunk c+1 (its mask is already in it)
     //   Kuse : K fragments of chunk c+1 (loaded one step ago)     Kld : receives the K fragments of chunk c+2
     // The caller alternates the two S / K buffers, so nothing is copied between steps.
-    auto step = [&](int c, f4 (&Sc)[CH][2], f4 (&Sn)[CH][2], const KVFrag<C>& Kuse, KVFrag<C>& Kld) {
+    auto step = [&](auto has_next, int c, f4 (&Sc)[CH][2], f4 (&Sn)[CH][2], const KVFrag<C>& Kuse, KVFrag<C>& Kld) {
       f4 va[CH][DT];
 #pragma unroll
       for (int t = 0; t < CH; ++t) {
@@ -392,12 +394,16 @@ EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, cons
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) va[t][dt] = ldg4(VTb + (size_t)(hd * DH + 16 * dt + fq) * ldv + (kt << 4) + 4 * g);
       }
-      load_k(hd, c + 2, Kld);
+      if (decltype(has_next)::value) load_k(hd, c + 2, Kld);
       __builtin_amdgcn_sched_barrier(0);
-      // scores of the NEXT chunk: independent MFMA work that overlaps this chunk's softmax VALU (same scheduling region).
-      // On the last chunk this recomputes a clamped chunk whose result is unused.
-      qk(Kuse, qa, qr, Sn);
-      f4 P[CH][2];
+      // scores of the NEXT chunk: independent MFMA work that overlaps this chunk's softmax VALU (same scheduling region)
+      if (decltype(has_next)::value) qk(Kuse, qa, qr, Sn);
+      // Online softmax with a DEFERRED running maximum: fp32 accumulators have ~2^127 of headroom, so the reference point
+      // m only has to move when a chunk exceeds it by more than 2^kDefer; until then P = 2^(s - m) <= 2^kDefer and neither O
+      // nor the row sums need rescaling (softmax is invariant to m).  The wave-uniform branch is taken on the first chunk
+      // (m starts at -1e30) and then only when some row's scores jump by > kDefer octaves; it removes the per-chunk
+      // read-modify-write of the O accumulators and the cross-lane max from the common path.
+      float mxl[2];
 #pragma unroll
       for (int ft = 0; ft < 2; ++ft) {
         f4 mv = Sc[0][ft];
@@ -405,20 +411,28 @@ EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, cons
         for (int t = 1; t < CH; ++t)
 #pragma unroll
           for (int r = 0; r < 4; ++r) mv[r] = fmaxf(mv[r], Sc[t][ft][r]);
-        const float mx = group_max(hmax(mv));
-        const float mnew = fmaxf(mrun[ft], mx);  // mrun starts at a finite -1e30, so exp2(-inf - mnew) = 0, never NaN
-        const float alpha = fast_exp2(mrun[ft] - mnew);
-        mrun[ft] = mnew;
-        f4 ps = splat(0.f);
+        mxl[ft] = hmax(mv);
+      }
+      if (__any((mxl[0] > mrun[0] + kDefer) || (mxl[1] > mrun[1] + kDefer))) {
+#pragma unroll
+        for (int ft = 0; ft < 2; ++ft) {
+          const float mnew = fmaxf(mrun[ft], group_max(mxl[ft]));  // identical on the 4 lanes of a row
+          const float alpha = fast_exp2(mrun[ft] - mnew);           // mrun starts finite (-1e30): never NaN
+          mrun[ft] = mnew;
+          lvec[ft] *= alpha;
+#pragma unroll
+          for (int dt = 0; dt < DT; ++dt) O[dt][ft] *= alpha;
+        }
+      }
+      f4 P[CH][2];
+#pragma unroll
+      for (int ft = 0; ft < 2; ++ft) {
 #pragma unroll
         for (int t = 0; t < CH; ++t) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) P[t][ft][r] = fast_exp2(Sc[t][ft][r] - mnew);
-          ps += P[t][ft];
+          for (int r = 0; r < 4; ++r) P[t][ft][r] = fast_exp2(Sc[t][ft][r] - mrun[ft]);
+          lvec[ft] += P[t][ft];
         }
-        lvec[ft] = lvec[ft] * alpha + ps;
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt) O[dt][ft] *= alpha;
       }
       // O^T += V^T P^T : DT x 2 independent accumulators, r outermost
 #pragma unroll
@@ -439,16 +453,21 @@ EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, cons
     mask_init(0, SA);
     __builtin_amdgcn_sched_barrier(0);
     qk(KA, qa, qr, SA);  // scores of chunk 0; KB holds chunk 1
+    using Yes = std::integral_constant<bool, true>;
+    using No = std::integral_constant<bool, false>;
     int c = 0;
-    for (; c + 1 < nchunk; c += 2) {
+    for (; c + 2 < nchunk; c += 2) {
       mask_init(c + 1, SB);
-      step(c, SA, SB, KB, KA);      // finishes chunk c,   scores of c+1 -> SB (from KB), loads K(c+2) -> KA
+      step(Yes{}, c, SA, SB, KB, KA);      // finishes chunk c,   scores of c+1 -> SB (from KB), loads K(c+2) -> KA
       mask_init(c + 2, SA);
-      step(c + 1, SB, SA, KA, KB);  // finishes chunk c+1, scores of c+2 -> SA (from KA), loads K(c+3) -> KB
+      step(Yes{}, c + 1, SB, SA, KA, KB);  // finishes chunk c+1, scores of c+2 -> SA (from KA), loads K(c+3) -> KB
     }
-    if (c < nchunk) {               // odd chunk count: last chunk's scores are in SA
+    if (nchunk - c == 2) {  // two chunks left: scores of c are in SA
       mask_init(c + 1, SB);
-      step(c, SA, SB, KB, KA);
+      step(Yes{}, c, SA, SB, KB, KA);
+      step(No{}, c + 1, SB, SA, KA, KB);
+    } else {                // one chunk left
+      step(No{}, c, SA, SB, KB, KA);
     }
     // ---- normalise and project: h[nt] += Wo[:, head features] . O ------------------------------------------
 #pragma unroll

@@ -264,3 +264,30 @@ def test_dsconv(golden):
         assert m.groups == int(g[f"{tag}_groups"])
         y = m(cu(g[f"{tag}_x"])).cpu()
         assert max_abs(y, g[f"{tag}_y"]) < 1e-5
+
+
+def test_forward_large_score_range():
+    """Forces the deferred-max rescale branch of the attention kernels (taken when a later key chunk exceeds the softmax
+    reference point by > 2^32): q/k projections scaled so that score ranges span hundreds of octaves, plus a spiked context
+    token.  Compared with the fp64 arbiter (saturated softmax is ill-conditioned in fp32 for BOTH implementations)."""
+    cfg = CFG(device=DEV)
+    sd = synth_state_dict(cfg, 0)
+    for l in range(cfg.layers):
+        sd[f"layers.{l}.attn.qkv.weight"][: 2 * cfg.hidden] *= 9.0      # q and k rows
+        sd[f"layers.{l}.cross_attn.q_proj.weight"] *= 9.0
+        sd[f"layers.{l}.cross_attn.kv_up_proj.weight"][: cfg.hidden] *= 9.0
+    dec = EdgeDiffusionDecoder(cfg)
+    dec.load_state_dict(sd)
+    dec = dec.to(DEV).eval()
+    gen = torch.Generator().manual_seed(4)
+    B, T, S = 2, 160, 80
+    x = torch.randn(B, T, 80, generator=gen) * 1.5
+    sem = torch.randint(0, 512, (B, S), generator=gen)
+    t, si = torch.tensor([700, 30]), torch.tensor([1, 2])
+    e = dec(cu(x), cu(t), cu(sem), cu(si)).cpu()
+    ref64 = O.decoder_forward(O.cast_sd(sd, torch.float64), x.double(), t, sem, si)
+    ref32 = O.decoder_forward(sd, x, t, sem, si)
+    ours, theirs = max_abs(e, ref64), max_abs(ref32, ref64)
+    print(f"large-score-range forward: ours vs fp64 {ours:.2e}, oracle fp32 vs fp64 {theirs:.2e}")
+    assert bool(torch.isfinite(e).all())
+    assert ours < max(5e-4, 20 * theirs)
