@@ -364,16 +364,33 @@ EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, cons
     }
   };
 
+  // q fragments (B operand: lane (fq,g) holds q[query][hd*DH + 16a + 4g + b]) and the K fragments of the first two chunks
+  // of a head.  They are fetched while the PREVIOUS head's projection phases run, so no head starts on an exposed load.
+  f4 qa_n[2][DFULL > 0 ? DFULL : 1];
+  f2 qr_n[2];
+  KVFrag<C> KA, KB;
+  auto prefetch_head = [&](int hd) {
+#pragma unroll
+    for (int ft = 0; ft < 2; ++ft) {
+#pragma unroll
+      for (int a = 0; a < DFULL; ++a) qa_n[ft][a] = qload.q4(ft, hd * DH + 16 * a + 4 * g);
+      if (DREM) qr_n[ft] = qload.q2(ft, hd * DH + 16 * DFULL + 2 * g);
+    }
+    load_k(hd, 0, KA);
+    load_k(hd, 1, KB);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  prefetch_head(0);
+
   for (int hd = 0; hd < C::HEADS; ++hd) {
-    // ---- q fragments of this head (B operand): lane (fq,g) holds q[query][hd*DH + 16a + 4g + b], pre-scaled by
-    //      log2(e)/sqrt(d) so the scores come out of the MFMA in the exp2 domain -------------------------------------
+    // pre-scale q by log2(e)/sqrt(d): the scores then come out of the MFMA in the exp2 domain
     f4 qa[2][DFULL > 0 ? DFULL : 1];
     f2 qr[2];
 #pragma unroll
     for (int ft = 0; ft < 2; ++ft) {
 #pragma unroll
-      for (int a = 0; a < DFULL; ++a) qa[ft][a] = qload.q4(ft, hd * DH + 16 * a + 4 * g) * c2;
-      if (DREM) qr[ft] = qload.q2(ft, hd * DH + 16 * DFULL + 2 * g) * c2;
+      for (int a = 0; a < DFULL; ++a) qa[ft][a] = qa_n[ft][a] * c2;
+      if (DREM) qr[ft] = qr_n[ft] * c2;
     }
     float mrun[2] = {-1e30f, -1e30f};
     f4 lvec[2] = {splat(0.f), splat(0.f)};  // per-lane partial row sums (reduced over r and the lane groups at the end)
@@ -446,12 +463,8 @@ EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, cons
           }
     };
 
-    KVFrag<C> KA, KB;
     f4 SA[CH][2], SB[CH][2];
-    load_k(hd, 0, KA);
-    load_k(hd, 1, KB);
     mask_init(0, SA);
-    __builtin_amdgcn_sched_barrier(0);
     qk(KA, qa, qr, SA);  // scores of chunk 0; KB holds chunk 1
     using Yes = std::integral_constant<bool, true>;
     using No = std::integral_constant<bool, false>;
@@ -477,6 +490,7 @@ EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, cons
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) O[dt][ft] *= inv;
     }
+    if (hd + 1 < C::HEADS) prefetch_head(hd + 1);
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) ktile_phase<C::HT>(ring, O[dt][0], O[dt][1], h);
   }

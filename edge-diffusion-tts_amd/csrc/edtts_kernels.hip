@@ -501,8 +501,9 @@ __global__ __launch_bounds__(C::THREADS) void k_layer(KArgs a) {
     }
     for (int j = 0; j < 2 * C::HT; ++j) {
       const f4 vb = ldg4(a.up_b + 32 * j + 4 * g), gb = ldg4(a.up_b + 32 * j + 16 + 4 * g);
-      f4 v0 = vb, v1 = vb, g0 = gb, g1 = gb;
+      f4 v0 = splat(0.f), v1 = splat(0.f), g0 = splat(0.f), g1 = splat(0.f);
       gemm_phase_pair<C::HT>(ring, hn, v0, v1, g0, g1);
+      v0 += vb; v1 += vb; g0 += gb; g1 += gb;  // bias after the GEMM: its load is off the MFMA critical path
       f4 act0, act1;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -533,8 +534,9 @@ __global__ __launch_bounds__(C::THREADS) void k_layer(KArgs a) {
 #pragma unroll
     for (int nt = 0; nt < C::MT; ++nt) {
       const f4 ob = ldg4(a.outp_b + 16 * nt + 4 * g);
-      f4 e0 = ob, e1 = ob;
+      f4 e0 = splat(0.f), e1 = splat(0.f);
       gemm_phase<C::HT>(ring, hn, e0, e1);
+      e0 += ob; e1 += ob;
 #pragma unroll
       for (int ft = 0; ft < 2; ++ft) {
         const int f = m0 + 16 * ft + fq;
