@@ -239,7 +239,8 @@ EDTTS_DEV void layer_norm_tile(const f4 (&x)[NT][2], const float* __restrict__ w
 }
 
 EDTTS_DEV float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
-EDTTS_DEV float silu(float g) { return g / (1.0f + __expf(-g)); }
+// g * sigmoid(g); v_rcp_f32 (1 ulp) instead of the 9-instruction IEEE divide -- relative error ~1e-7, far inside the parity budget
+EDTTS_DEV float silu(float g) { return g * __builtin_amdgcn_rcpf(1.0f + __expf(-g)); }
 
 // ---------------------------------------------------------------------------------------------------------
 // Multi-head attention for one wave's 32 query frames, fused with the output projection:
