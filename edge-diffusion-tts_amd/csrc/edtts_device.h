@@ -271,6 +271,11 @@ struct KVFrag {  // MFMA A operands of one chunk of key tiles, for one head
   f2 kr[kChunk];
 };
 
+template <class C>
+struct VFrag {  // V^T fragments (MFMA A operand of P V) of one chunk of key tiles, for one head
+  f4 v[kChunk][C::DT];
+};
+
 template <class C, bool SELF, class QLoad>
 EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, const float* __restrict__ VTb, int ldv,
                                int nkeys, int window, int m0, int lane, WStream<C>& ring, f4 (&h)[C::HT][2]) {
@@ -317,6 +322,16 @@ EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, cons
 #pragma unroll
       for (int a = 0; a < DFULL; ++a) f.ka[t][a] = ldg4(kp + 16 * a + 4 * g);
       if (DREM) f.kr[t] = ldg2(kp + 16 * DFULL + 2 * g);
+    }
+  };
+  auto load_v = [&](int hd, int c, VFrag<C>& f) {
+    c = c < nchunk ? c : nchunk - 1;
+#pragma unroll
+    for (int t = 0; t < CH; ++t) {
+      int kt = kt_lo + c * CH + t;
+      kt = kt < kt_hi ? kt : kt_hi - 1;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) f.v[t][dt] = ldg4(VTb + (size_t)(hd * DH + 16 * dt + fq) * ldv + (kt << 4) + 4 * g);
     }
   };
   // Mask of chunk c as the INITIAL accumulator of its K Q^T product: 0 where the key is visible, -inf elsewhere
@@ -370,6 +385,7 @@ EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, cons
   f4 qa_n[2][DFULL > 0 ? DFULL : 1];
   f2 qr_n[2];
   KVFrag<C> KA, KB;
+  VFrag<C> VA, VB;
   auto prefetch_head = [&](int hd) {
 #pragma unroll
     for (int ft = 0; ft < 2; ++ft) {
@@ -379,6 +395,7 @@ EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, cons
     }
     load_k(hd, 0, KA);
     load_k(hd, 1, KB);
+    load_v(hd, 0, VA);
     __builtin_amdgcn_sched_barrier(0);
   };
   prefetch_head(0);
@@ -402,17 +419,16 @@ EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, cons
     // One step: finish chunk c (softmax + P V) while the scores of chunk c+1 are produced.
     //   Sc   : scores of chunk c (complete)          Sn : receives the scores of chunk c+1 (its mask is already in it)
     //   Kuse : K fragments of chunk c+1 (loaded one step ago)     Kld : receives the K fragments of chunk c+2
-    // The caller alternates the two S / K buffers, so nothing is copied between steps.
-    auto step = [&](auto has_next, int c, f4 (&Sc)[CH][2], f4 (&Sn)[CH][2], const KVFrag<C>& Kuse, KVFrag<C>& Kld) {
-      f4 va[CH][DT];
-#pragma unroll
-      for (int t = 0; t < CH; ++t) {
-        int kt = kt_lo + c * CH + t;
-        kt = kt < kt_hi ? kt : kt_hi - 1;
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt) va[t][dt] = ldg4(VTb + (size_t)(hd * DH + 16 * dt + fq) * ldv + (kt << 4) + 4 * g);
+    //   Vuse : V^T fragments of chunk c (loaded one step ago)     Vld : receives the V^T fragments of chunk c+1
+    // Every load is consumed in a LATER step (loop-carried), which is what keeps hipcc from sinking it next to its use:
+    // a V load issued and used within the same step was moved across the rescale branch right in front of the P V MFMAs.
+    // The caller alternates the S / K / V buffers, so nothing is copied between steps.
+    auto step = [&](auto has_next, int c, f4 (&Sc)[CH][2], f4 (&Sn)[CH][2], const KVFrag<C>& Kuse, KVFrag<C>& Kld,
+                    const VFrag<C>& Vuse, VFrag<C>& Vld) {
+      if (decltype(has_next)::value) {
+        load_v(hd, c + 1, Vld);
+        load_k(hd, c + 2, Kld);
       }
-      if (decltype(has_next)::value) load_k(hd, c + 2, Kld);
       __builtin_amdgcn_sched_barrier(0);
       // scores of the NEXT chunk: independent MFMA work that overlaps this chunk's softmax VALU (same scheduling region)
       if (decltype(has_next)::value) qk(Kuse, qa, qr, Sn);
@@ -459,8 +475,8 @@ EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, cons
         for (int r = 0; r < 4; ++r)
 #pragma unroll
           for (int dt = 0; dt < DT; ++dt) {
-            O[dt][0] = EDTTS_MFMA(va[t][dt][r], P[t][0][r], O[dt][0]);
-            O[dt][1] = EDTTS_MFMA(va[t][dt][r], P[t][1][r], O[dt][1]);
+            O[dt][0] = EDTTS_MFMA(Vuse.v[t][dt][r], P[t][0][r], O[dt][0]);
+            O[dt][1] = EDTTS_MFMA(Vuse.v[t][dt][r], P[t][1][r], O[dt][1]);
           }
     };
 
@@ -472,16 +488,16 @@ EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, cons
     int c = 0;
     for (; c + 2 < nchunk; c += 2) {
       mask_init(c + 1, SB);
-      step(Yes{}, c, SA, SB, KB, KA);      // finishes chunk c,   scores of c+1 -> SB (from KB), loads K(c+2) -> KA
+      step(Yes{}, c, SA, SB, KB, KA, VA, VB);      // finishes chunk c; scores of c+1 -> SB (from KB); loads K(c+2) -> KA, V(c+1) -> VB
       mask_init(c + 2, SA);
-      step(Yes{}, c + 1, SB, SA, KA, KB);  // finishes chunk c+1, scores of c+2 -> SA (from KA), loads K(c+3) -> KB
+      step(Yes{}, c + 1, SB, SA, KA, KB, VB, VA);  // finishes chunk c+1; scores of c+2 -> SA (from KA); loads K(c+3) -> KB, V(c+2) -> VA
     }
-    if (nchunk - c == 2) {  // two chunks left: scores of c are in SA
+    if (nchunk - c == 2) {  // two chunks left: scores of c are in SA, V(c) in VA
       mask_init(c + 1, SB);
-      step(Yes{}, c, SA, SB, KB, KA);
-      step(No{}, c + 1, SB, SA, KA, KB);
+      step(Yes{}, c, SA, SB, KB, KA, VA, VB);
+      step(No{}, c + 1, SB, SA, KA, KB, VB, VA);
     } else {                // one chunk left
-      step(No{}, c, SA, SB, KB, KA);
+      step(No{}, c, SA, SB, KB, KA, VA, VB);
     }
     // ---- normalise and project: h[nt] += Wo[:, head features] . O ------------------------------------------
 #pragma unroll
