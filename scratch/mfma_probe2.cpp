@@ -185,6 +185,50 @@ __global__ __launch_bounds__(256) void stream16c(const f32x4* __restrict__ wp, f
   out[(blockIdx.x * blockDim.x + threadIdx.x)] = s[0] + s[1] + s[2] + s[3];
 }
 
+// variant: fragment addresses = wave-uniform base (SGPR) + constant per-lane byte offset (no per-load VALU address math)
+template <int KT, int NT, int NF>
+__global__ __launch_bounds__(256) void stream16d(const f32x4* __restrict__ wp, float* out, int reps) {
+  const int lane = threadIdx.x & 63;
+  const unsigned loff = lane * 16;
+  f32x4 in[KT][NF];
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+    for (int ft = 0; ft < NF; ++ft) in[kt][ft] = f32x4{0.37f * lane + kt, 1.1f, 0.3f * ft, 0.5f};
+  f32x4 sum[NF];
+#pragma unroll
+  for (int ft = 0; ft < NF; ++ft) sum[ft] = f32x4{0, 0, 0, 0};
+  for (int rep = 0; rep < reps; ++rep) {
+    const char* base = (const char*)wp;  // uniform
+    f32x4 frag[KT];
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) frag[kt] = *(const f32x4*)(base + kt * 1024 + loff);
+    for (int nt = 0; nt < NT; ++nt) {
+      f32x4 acc[2][NF];
+#pragma unroll
+      for (int ft = 0; ft < NF; ++ft) acc[0][ft] = acc[1][ft] = f32x4{0, 0, 0, 0};
+      const char* nb = base + (nt + 1 < NT ? KT * 1024 : 0);
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int ft = 0; ft < NF; ++ft)
+            acc[kt & 1][ft] = __builtin_amdgcn_mfma_f32_16x16x4f32(frag[kt][r], in[kt][ft][r], acc[kt & 1][ft], 0, 0, 0);
+        frag[kt] = *(const f32x4*)(nb + kt * 1024 + loff);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      base = nb;
+#pragma unroll
+      for (int ft = 0; ft < NF; ++ft) sum[ft] += acc[0][ft] + acc[1][ft];
+    }
+  }
+  f32x4 s = sum[0];
+#pragma unroll
+  for (int ft = 1; ft < NF; ++ft) s += sum[ft];
+  out[(blockIdx.x * blockDim.x + threadIdx.x)] = s[0] + s[1] + s[2] + s[3];
+}
+
 template <class F> void timeit(const char* name, F launch, double flops) {
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   launch(1); CK(hipDeviceSynchronize());
@@ -210,6 +254,7 @@ int main() {
   timeit("16x16x4 NF=2 splitK refill LAG=1", [&](int r) { stream16c<KT, NT, 2, 1><<<blocks, 256>>>(dW + 640, dO, r); }, f16 * 2);
   timeit("16x16x4 NF=2 splitK refill LAG=2", [&](int r) { stream16c<KT, NT, 2, 2><<<blocks, 256>>>(dW + 640, dO, r); }, f16 * 2);
   timeit("16x16x4 NF=2 splitK refill LAG=0", [&](int r) { stream16c<KT, NT, 2, 0><<<blocks, 256>>>(dW + 640, dO, r); }, f16 * 2);
+  timeit("16x16x4 NF=2 splitK saddr-base loads", [&](int r) { stream16d<KT, NT, 2><<<blocks, 256>>>(dW, dO, r); }, f16 * 2);
   timeit("16x16x4 NF=4 loads refill-after-use", [&](int r) { stream16b<KT, NT, 4, false><<<blocks, 256>>>(dW, dO, r); }, f16 * 4);
   timeit("16x16x4 NF=2 no loads", [&](int r) { stream16<KT, NT, 2, false><<<blocks, 256>>>(dW, dO, r); }, f16 * 2);
   timeit("16x16x4 NF=4 loads", [&](int r) { stream16<KT, NT, 4, true><<<blocks, 256>>>(dW, dO, r); }, f16 * 4);
