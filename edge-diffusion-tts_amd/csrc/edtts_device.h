@@ -25,12 +25,16 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 
 namespace edtts {
 
-constexpr int kWaveFrames = 32;  // frames per wave
 constexpr int kCtxWaves = 4;     // waves per block of the context kernel (no block-level sharing there)
 
-template <int H_, int HEADS_, int MEL_>
+// NF = 16-frame tiles per wave.  Every weight fragment (1 KiB) feeds 4*NF MFMAs, and the bare register-chained stream
+// measures 141 TFLOP/s at NF = 2 against 150 at NF = 4 (scratch/mfma_probe2.cpp), so the default decoder runs NF = 4
+// (64 frames per wave, the residual tile alone is 160 registers); attention works on pairs of frame tiles at a time.
+template <int H_, int HEADS_, int MEL_, int NF_ = 2>
 struct Cfg {
-  static constexpr int H = H_, HEADS = HEADS_, MEL = MEL_;
+  static constexpr int H = H_, HEADS = HEADS_, MEL = MEL_, NF = NF_;
+  static constexpr int WF = 16 * NF;              // frames per wave
+  static constexpr int NHALF = NF / 2;            // attention passes per wave (2 frame tiles each)
   static constexpr int DH = H / HEADS;            // head dim (40 for the default decoder)
   static constexpr int DFULL = DH / 16;           // full 16-wide groups of the head dim
   static constexpr int DREM = DH % 16;            // remainder (0 or 8 supported)
@@ -40,9 +44,13 @@ struct Cfg {
   static constexpr int MT = MEL / 16;             // feature tiles of the mel dim
   static constexpr int R = H / 2, RT = R / 16;    // kv_lora_rank (transformer.py:113) and its tiles
   static constexpr int VR = (HEADS - 1) * DH + DHP;  // rows of a V^T buffer (last head padded)
-  static constexpr int QLD = H + 4;               // LDS row stride (floats) of the cross-attention q tile
-  static constexpr int WAVES = H > 192 ? 2 : 4;   // waves per block: bounded by LDS (weight ring + one q tile per wave)
+  static constexpr int WAVES = H > 192 ? (NF == 2 ? 2 : 1) : 4;  // waves per block (bounded by the LDS q tiles)
+  // LDS row stride (floats) of the cross-attention q tile: padded by 4 when it fits, unpadded when 4 waves x WF rows
+  // would otherwise exceed the 160 KiB of the CU
+  static constexpr int QLD = (WAVES * WF * (H + 4) * 4 <= 160 * 1024) ? H + 4 : H;
   static constexpr int THREADS = 64 * WAVES;
+  static_assert(WAVES * WF * QLD * 4 <= 160 * 1024, "q tiles exceed LDS");
+  static_assert(NF == 2 || NF == 4, "frame tiles per wave");
   static_assert(H % 32 == 0 && MEL % 16 == 0 && H % HEADS == 0, "dims");
   static_assert(DREM == 0 || DREM == 8, "head_dim % 16 must be 0 or 8");
 };
@@ -84,7 +92,7 @@ EDTTS_DEV float hmax(f4 v) { return fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
 // Weight fragment stream.  The packed weights of a kernel are laid out in CONSUMPTION order as one linear stream of
 // 1-KiB fragments.  FragRing<RN> keeps the next RN fragments in registers: position i of the current phase lives in
 // slot i % RN, and once the MFMAs that read a slot have been ISSUED the slot is refilled with stream element i + RN
-// (prefetch distance RN fragments = 8*RN MFMAs; RN must divide every phase length).  Refilling after use matters:
+// (prefetch distance RN fragments = 4*NF*RN MFMAs; RN must divide every phase length).  Refilling after use matters:
 // loading into the slot before its old value is consumed makes hipcc copy the whole ring and wait for every load at
 // the top of each phase (measured 126 -> 137 TFLOP/s on the bare stream).  The sched_barrier pins the issue point:
 // without it the pre-RA scheduler sinks each load to its use RN fragments later, i.e. load -> s_waitcnt -> MFMA.
@@ -106,37 +114,41 @@ struct FragRing {
   EDTTS_DEV void advance(int n) { p += n * 64; }
 };
 
-// out^T tile (16 features x 32 frames) += sum_kt frag(kt) * in[kt]: one n-major phase of KT fragments.  Even / odd k-tiles
-// go to separate accumulators (4 independent MFMA chains per wave: v_mfma_f32_16x16x4_f32 has a 40-cycle dependent
-// latency at a 32-cycle issue interval) and are summed at the end, which also halves each fp32 summation chain.
-template <int KT, int RN>
-EDTTS_DEV void gemm_phase(FragRing<RN>& ring, const f4 (&in)[KT][2], f4& acc0, f4& acc1) {
+// out^T tile (16 features x 16*NF frames) += sum_kt frag(kt) * in[kt]: one n-major phase of KT fragments.  At NF = 2 even /
+// odd k-tiles go to separate accumulators and are summed at the end, so that 4 independent MFMA chains are in flight
+// (v_mfma_f32_16x16x4_f32: 32-cycle issue, 40-cycle dependent latency); at NF = 4 the frame tiles are the 4 chains.
+template <int KT, int RN, int NF>
+EDTTS_DEV void gemm_phase(FragRing<RN>& ring, const f4 (&in)[KT][NF], f4 (&acc)[NF]) {
   static_assert(KT % RN == 0, "phase length must be a multiple of the ring size");
-  f4 b0 = splat(0.f), b1 = splat(0.f);
+  constexpr bool SPLIT = NF < 4;
+  f4 b[NF];
+  if (SPLIT) {
+#pragma unroll
+    for (int ft = 0; ft < NF; ++ft) b[ft] = splat(0.f);
+  }
 #pragma unroll
   for (int kt = 0; kt < KT; ++kt) {
     const f4& a = ring.at(kt);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      if (kt & 1) {
-        b0 = EDTTS_MFMA(a[r], in[kt][0][r], b0);
-        b1 = EDTTS_MFMA(a[r], in[kt][1][r], b1);
-      } else {
-        acc0 = EDTTS_MFMA(a[r], in[kt][0][r], acc0);
-        acc1 = EDTTS_MFMA(a[r], in[kt][1][r], acc1);
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int ft = 0; ft < NF; ++ft) {
+        if (SPLIT && (kt & 1)) b[ft] = EDTTS_MFMA(a[r], in[kt][ft][r], b[ft]);
+        else acc[ft] = EDTTS_MFMA(a[r], in[kt][ft][r], acc[ft]);
       }
-    }
     ring.refill(kt);
   }
-  acc0 += b0;
-  acc1 += b1;
+  if (SPLIT) {
+#pragma unroll
+    for (int ft = 0; ft < NF; ++ft) acc[ft] += b[ft];
+  }
   ring.advance(KT);
 }
 
-// Two n-tiles at once from a stream that interleaves their fragments per k-tile ([kt][tile a | tile b]): the four
-// accumulators are the four independent chains.  Used for the FFN value/gate pair (layers/transformer.py:21-23).
-template <int KT, int RN>
-EDTTS_DEV void gemm_phase_pair(FragRing<RN>& ring, const f4 (&in)[KT][2], f4& a0, f4& a1, f4& b0, f4& b1) {
+// Two n-tiles at once from a stream that interleaves their fragments per k-tile ([kt][tile a | tile b]).
+// Used for the FFN value/gate pair (layers/transformer.py:21-23).
+template <int KT, int RN, int NF>
+EDTTS_DEV void gemm_phase_pair(FragRing<RN>& ring, const f4 (&in)[KT][NF], f4 (&a)[NF], f4 (&b)[NF]) {
   static_assert((2 * KT) % RN == 0, "phase length must be a multiple of the ring size");
 #pragma unroll
   for (int kt = 0; kt < KT; ++kt) {
@@ -144,10 +156,10 @@ EDTTS_DEV void gemm_phase_pair(FragRing<RN>& ring, const f4 (&in)[KT][2], f4& a0
     const f4& fb = ring.at(2 * kt + 1);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      a0 = EDTTS_MFMA(fa[r], in[kt][0][r], a0);
-      a1 = EDTTS_MFMA(fa[r], in[kt][1][r], a1);
-      b0 = EDTTS_MFMA(fb[r], in[kt][0][r], b0);
-      b1 = EDTTS_MFMA(fb[r], in[kt][1][r], b1);
+#pragma unroll
+      for (int ft = 0; ft < NF; ++ft) a[ft] = EDTTS_MFMA(fa[r], in[kt][ft][r], a[ft]);
+#pragma unroll
+      for (int ft = 0; ft < NF; ++ft) b[ft] = EDTTS_MFMA(fb[r], in[kt][ft][r], b[ft]);
     }
     ring.refill(2 * kt);
     ring.refill(2 * kt + 1);
@@ -155,26 +167,26 @@ EDTTS_DEV void gemm_phase_pair(FragRing<RN>& ring, const f4 (&in)[KT][2], f4& a0
   ring.advance(2 * KT);
 }
 
-// acc[nt] += frag(nt) * in   for one k-tile of a k-major packed matrix (NT fragments); two n-tiles are interleaved so
-// that four accumulator chains are in flight.
-template <int NT, int RN>
-EDTTS_DEV void ktile_phase(FragRing<RN>& ring, f4 in0, f4 in1, f4 (&acc)[NT][2]) {
+// acc[nt] += frag(nt) * in   for one k-tile of a k-major packed matrix (NT fragments).  At NF = 2 two n-tiles are
+// interleaved so that four accumulator chains are in flight.
+template <int NT, int RN, int NF>
+EDTTS_DEV void ktile_phase(FragRing<RN>& ring, const f4 (&in)[NF], f4 (&acc)[NT][NF]) {
   static_assert(NT % RN == 0, "phase length must be a multiple of the ring size");
+  constexpr int STEP = NF < 4 ? 2 : 1;
 #pragma unroll
-  for (int nt = 0; nt < NT; nt += 2) {
-    const f4& fa = ring.at(nt);
-    const f4& fb = ring.at(nt + 1 < NT ? nt + 1 : nt);
+  for (int nt = 0; nt < NT; nt += STEP) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      acc[nt][0] = EDTTS_MFMA(fa[r], in0[r], acc[nt][0]);
-      acc[nt][1] = EDTTS_MFMA(fa[r], in1[r], acc[nt][1]);
-      if (nt + 1 < NT) {
-        acc[nt + 1][0] = EDTTS_MFMA(fb[r], in0[r], acc[nt + 1][0]);
-        acc[nt + 1][1] = EDTTS_MFMA(fb[r], in1[r], acc[nt + 1][1]);
-      }
-    }
-    ring.refill(nt);
-    if (nt + 1 < NT) ring.refill(nt + 1);
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int u = 0; u < STEP; ++u)
+        if (nt + u < NT) {
+          const f4& fa = ring.at(nt + u);
+#pragma unroll
+          for (int ft = 0; ft < NF; ++ft) acc[nt + u][ft] = EDTTS_MFMA(fa[r], in[ft][r], acc[nt + u][ft]);
+        }
+#pragma unroll
+    for (int u = 0; u < STEP; ++u)
+      if (nt + u < NT) ring.refill(nt + u);
   }
   ring.advance(NT);
 }
@@ -184,57 +196,60 @@ EDTTS_DEV void ktile_phase(FragRing<RN>& ring, f4 in0, f4 in1, f4 (&acc)[NT][2])
 // ---------------------------------------------------------------------------------------------------------
 // RMSNorm (layers/mla.py:46-58): x * rsqrt(mean(x^2) + 1e-6) * w ; optional AdaLN modulation
 // (layers/transformer.py:64-68): y * (1 + scale) + shift, with mod = {1+scale [H], shift [H]} rows.
-template <int NT>
-EDTTS_DEV void rms_norm_tile(const f4 (&x)[NT][2], const float* __restrict__ w, const float* __restrict__ mod, int g,
-                             f4 (&y)[NT][2]) {
+template <int NT, int NF>
+EDTTS_DEV void rms_norm_tile(const f4 (&x)[NT][NF], const float* __restrict__ w, const float* __restrict__ mod, int g,
+                             f4 (&y)[NT][NF]) {
   constexpr int N = NT * 16;
-  float ss0 = 0.f, ss1 = 0.f;
+  float rs[NF];
 #pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    ss0 += hsum(x[t][0] * x[t][0]);
-    ss1 += hsum(x[t][1] * x[t][1]);
+  for (int ft = 0; ft < NF; ++ft) {
+    float ss = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) ss += hsum(x[t][ft] * x[t][ft]);
+    rs[ft] = rsqrtf(group_sum(ss) * (1.0f / N) + 1e-6f);
   }
-  const float r0 = rsqrtf(group_sum(ss0) * (1.0f / N) + 1e-6f);
-  const float r1 = rsqrtf(group_sum(ss1) * (1.0f / N) + 1e-6f);
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     const f4 wv = ldg4(w + 16 * t + 4 * g);
-    f4 a = x[t][0] * r0 * wv, b = x[t][1] * r1 * wv;
+    f4 sc = splat(1.f), sh = splat(0.f);
     if (mod != nullptr) {
-      const f4 sc = ldg4(mod + 16 * t + 4 * g), sh = ldg4(mod + N + 16 * t + 4 * g);
-      a = a * sc + sh;
-      b = b * sc + sh;
+      sc = ldg4(mod + 16 * t + 4 * g);
+      sh = ldg4(mod + N + 16 * t + 4 * g);
     }
-    y[t][0] = a;
-    y[t][1] = b;
+#pragma unroll
+    for (int ft = 0; ft < NF; ++ft) {
+      f4 a = x[t][ft] * rs[ft] * wv;
+      if (mod != nullptr) a = a * sc + sh;
+      y[t][ft] = a;
+    }
   }
 }
 
 // LayerNorm(eps 1e-5, affine) (models/decoder.py:59,108)
-template <int NT>
-EDTTS_DEV void layer_norm_tile(const f4 (&x)[NT][2], const float* __restrict__ w, const float* __restrict__ b, int g,
-                               f4 (&y)[NT][2]) {
+template <int NT, int NF>
+EDTTS_DEV void layer_norm_tile(const f4 (&x)[NT][NF], const float* __restrict__ w, const float* __restrict__ b, int g,
+                               f4 (&y)[NT][NF]) {
   constexpr int N = NT * 16;
-  float s0 = 0.f, s1 = 0.f;
+  float mu[NF], rs[NF];
 #pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    s0 += hsum(x[t][0]);
-    s1 += hsum(x[t][1]);
-  }
-  const float mu0 = group_sum(s0) * (1.0f / N), mu1 = group_sum(s1) * (1.0f / N);
-  float v0 = 0.f, v1 = 0.f;
+  for (int ft = 0; ft < NF; ++ft) {
+    float s = 0.f;
 #pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    const f4 d0 = x[t][0] - mu0, d1 = x[t][1] - mu1;
-    v0 += hsum(d0 * d0);
-    v1 += hsum(d1 * d1);
+    for (int t = 0; t < NT; ++t) s += hsum(x[t][ft]);
+    mu[ft] = group_sum(s) * (1.0f / N);
+    float v = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const f4 d = x[t][ft] - mu[ft];
+      v += hsum(d * d);
+    }
+    rs[ft] = rsqrtf(group_sum(v) * (1.0f / N) + 1e-5f);
   }
-  const float r0 = rsqrtf(group_sum(v0) * (1.0f / N) + 1e-5f), r1 = rsqrtf(group_sum(v1) * (1.0f / N) + 1e-5f);
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     const f4 wv = ldg4(w + 16 * t + 4 * g), bv = ldg4(b + 16 * t + 4 * g);
-    y[t][0] = (x[t][0] - mu0) * r0 * wv + bv;
-    y[t][1] = (x[t][1] - mu1) * r1 * wv + bv;
+#pragma unroll
+    for (int ft = 0; ft < NF; ++ft) y[t][ft] = (x[t][ft] - mu[ft]) * rs[ft] * wv + bv;
   }
 }
 
@@ -242,25 +257,13 @@ EDTTS_DEV float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 // g * sigmoid(g); v_rcp_f32 (1 ulp) instead of the 9-instruction IEEE divide -- relative error ~1e-7, far inside the parity budget
 EDTTS_DEV float silu(float g) { return g * __builtin_amdgcn_rcpf(1.0f + __expf(-g)); }
 
-// ---------------------------------------------------------------------------------------------------------
-// Multi-head attention for one wave's 32 query frames, fused with the output projection:
-//   h += W_o . concat_heads( softmax(q k^T / sqrt(d) [band mask]) v )
-// q comes from global memory (SELF: the q rows written by the previous kernel) or from this wave's LDS tile
-// (cross-attention); K is row-major [key][H]; V is stored transposed [feature][key] so that both MFMA A operands
-// are 16-byte loads.  Scores live only in registers: S^T tile = K Q^T (keys on MFMA rows, queries on lanes), an
-// online softmax over 16-key tiles, and P^T (the C/D registers) is directly the B operand of O^T = V^T P^T.
-// The per-head output tiles O^T[dt] then feed the k-major projection weights from the fragment ring.
-//   SELF : keys are frames of the same utterance, band |i-j| <= window (layers/attention.py:27-30,108-112)
-//   !SELF: keys are the S context tokens, no mask (layers/mla.py:158-179)
-// ---------------------------------------------------------------------------------------------------------
-// weight stream of the layer / prologue kernels: a per-wave register ring of HT/2 fragments straight from L2.
+// weight stream of the layer / prologue kernels: a per-wave register ring of HT fragments straight from L2; the four waves
+// of a block share each fragment through the CU's L1 (measured 86 % TCP hit rate).
 // (A block-shared LDS ring -- each fragment fetched once per block, ds_read_b128 to the MFMA -- was built and measured:
-// 6 % slower at B=256, T=512, because its per-phase block barrier costs more than the 4x L2 traffic it saves; see
+// 6 % slower at B=256, T=512, because its per-phase block barrier costs more than the L2 traffic it saves; see
 // DESIGN.md "What was tried".)
-#ifndef EDTTS_RING_DIV
-#define EDTTS_RING_DIV 1
-#endif
-template <class C> using WStream = FragRing<(C::HT / EDTTS_RING_DIV >= 2 ? C::HT / EDTTS_RING_DIV : 2)>;
+// Ring size: HT fragments at NF = 2, HT/2 at NF = 4 -- the same prefetch distance in MFMAs (4*NF per fragment).
+template <class C> using WStream = FragRing<((C::HT * 2) / C::NF >= 2 && C::HT % ((C::HT * 2) / C::NF) == 0 ? (C::HT * 2) / C::NF : C::HT)>;
 
 constexpr int kChunk = 2;  // key tiles (16 keys each) per online-softmax step
 constexpr float kDefer = 32.f;  // octaves a chunk may exceed the softmax reference point before it is moved
@@ -276,81 +279,103 @@ struct VFrag {  // V^T fragments (MFMA A operand of P V) of one chunk of key til
   f4 v[kChunk][C::DT];
 };
 
+// ---------------------------------------------------------------------------------------------------------
+// Multi-head attention for one wave's 16*NF query frames, fused with the output projection:
+//   h += W_o . concat_heads( softmax(q k^T / sqrt(d) [band mask]) v )
+// q comes from global memory (SELF: the q rows written by the previous kernel) or from this wave's LDS tile
+// (cross-attention); K is row-major [key][H]; V is stored transposed [feature][key] so that both MFMA A operands
+// are 16-byte loads.  Scores live only in registers: S^T tile = K Q^T (keys on MFMA rows, queries on lanes), an online
+// softmax over 32-key chunks, and P^T (the C/D registers) is directly the B operand of O^T = V^T P^T.  The attention
+// proper runs on PAIRS of query tiles ("halves" of 32 frames, NF/2 per wave); the per-head outputs O^T[dt] of all NF
+// tiles then feed the k-major projection weights from the fragment ring in one NF-wide phase.
+//   SELF : keys are frames of the same utterance, band |i-j| <= window (layers/attention.py:27-30,108-112)
+//   !SELF: keys are the S context tokens, no mask (layers/mla.py:158-179)
+// qload.q4(row16, col) / q2(...) return q[m0 + 16*row16 + fq][col...] for this lane.
+// ---------------------------------------------------------------------------------------------------------
 template <class C, bool SELF, class QLoad>
 EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, const float* __restrict__ VTb, int ldv,
-                               int nkeys, int window, int m0, int lane, WStream<C>& ring, f4 (&h)[C::HT][2]) {
-  constexpr int DH = C::DH, DFULL = C::DFULL, DREM = C::DREM, DT = C::DT, H = C::H, CH = kChunk;
+                               int nkeys, int window, int m0w, int lane, WStream<C>& ring, f4 (&h)[C::HT][C::NF]) {
+  constexpr int DH = C::DH, DFULL = C::DFULL, DREM = C::DREM, DT = C::DT, H = C::H, CH = kChunk, NF = C::NF;
+  constexpr int NHALF = C::NHALF;
   const int fq = lane & 15, g = lane >> 4;
   // softmax in base 2: p = 2^((s - m) * c), c = log2(e) / sqrt(d)
   const float c2 = 1.4426950408889634f * rsqrtf((float)DH);
   const float NEG_INF = -__builtin_inff();
-  int kt_lo, kt_hi;
-  if (SELF && window >= 0) {
-    const int lo = m0 - window;
-    kt_lo = (lo > 0 ? lo : 0) >> 4;
-    const int hi = m0 + kWaveFrames - 1 + window;  // last key any query of this wave may see
-    const int last = (hi < nkeys - 1 ? hi : nkeys - 1);
-    kt_hi = (last >> 4) + 1;
-  } else {
-    kt_lo = 0;
-    kt_hi = (nkeys + 15) >> 4;
-  }
-  const int nchunk = (kt_hi - kt_lo + CH - 1) / CH;
-  const int klim = (kt_hi << 4) < nkeys ? (kt_hi << 4) : nkeys;  // keys >= klim are never valid
-  // per-lane band limits on d = key - query:  lo_d <= d <= hi_d   (one unsigned compare per score)
-  int lo_d[2], span[2];
-#pragma unroll
-  for (int ft = 0; ft < 2; ++ft) {
-    const int qi = m0 + 16 * ft + fq;
-    int lo = -(1 << 28), hi = klim - 1 - qi;
-    if (SELF && window >= 0) {
-      lo = -window;
-      hi = hi < window ? hi : window;
-    }
-    lo_d[ft] = lo;
-    span[ft] = hi - lo;  // negative -> nothing valid
-  }
 
-  // loads of one chunk's K fragments (tile index clamped: tiles past kt_hi are fully masked by klim)
-  auto load_k = [&](int hd, int c, KVFrag<C>& f) {
-    c = c < nchunk ? c : nchunk - 1;
+  // per-half geometry (a half = 32 query frames starting at m0 = m0w + 32*half)
+  struct Geo {
+    int m0, kt_lo, kt_hi, nchunk, klim;
+    int lo_d[2], span[2];  // per-lane band limits on d = key - query: valid <=> (unsigned)(d - lo_d) <= span
+  };
+  auto make_geo = [&](int half) {
+    Geo q;
+    q.m0 = m0w + 32 * half;
+    if (SELF && window >= 0) {
+      const int lo = q.m0 - window;
+      q.kt_lo = (lo > 0 ? lo : 0) >> 4;
+      const int hi = q.m0 + 31 + window;  // last key any query of this half may see
+      const int last = (hi < nkeys - 1 ? hi : nkeys - 1);
+      q.kt_hi = (last >> 4) + 1;
+    } else {
+      q.kt_lo = 0;
+      q.kt_hi = (nkeys + 15) >> 4;
+    }
+    q.nchunk = (q.kt_hi - q.kt_lo + CH - 1) / CH;
+    q.klim = (q.kt_hi << 4) < nkeys ? (q.kt_hi << 4) : nkeys;  // keys >= klim are never valid
+#pragma unroll
+    for (int ft = 0; ft < 2; ++ft) {
+      const int qi = q.m0 + 16 * ft + fq;
+      int lo = -(1 << 28), hi = q.klim - 1 - qi;
+      if (SELF && window >= 0) {
+        lo = -window;
+        hi = hi < window ? hi : window;
+      }
+      q.lo_d[ft] = lo;
+      q.span[ft] = hi - lo;  // negative -> nothing valid
+    }
+    return q;
+  };
+
+  // loads of one chunk's K / V^T fragments (tile index clamped: tiles past kt_hi are fully masked by klim)
+  auto load_k = [&](const Geo& q, int hd, int c, KVFrag<C>& f) {
+    c = c < q.nchunk ? c : q.nchunk - 1;
 #pragma unroll
     for (int t = 0; t < CH; ++t) {
-      int kt = kt_lo + c * CH + t;
-      kt = kt < kt_hi ? kt : kt_hi - 1;
+      int kt = q.kt_lo + c * CH + t;
+      kt = kt < q.kt_hi ? kt : q.kt_hi - 1;
       const float* kp = Kb + (size_t)((kt << 4) + fq) * H + hd * DH;
 #pragma unroll
       for (int a = 0; a < DFULL; ++a) f.ka[t][a] = ldg4(kp + 16 * a + 4 * g);
       if (DREM) f.kr[t] = ldg2(kp + 16 * DFULL + 2 * g);
     }
   };
-  auto load_v = [&](int hd, int c, VFrag<C>& f) {
-    c = c < nchunk ? c : nchunk - 1;
+  auto load_v = [&](const Geo& q, int hd, int c, VFrag<C>& f) {
+    c = c < q.nchunk ? c : q.nchunk - 1;
 #pragma unroll
     for (int t = 0; t < CH; ++t) {
-      int kt = kt_lo + c * CH + t;
-      kt = kt < kt_hi ? kt : kt_hi - 1;
+      int kt = q.kt_lo + c * CH + t;
+      kt = kt < q.kt_hi ? kt : q.kt_hi - 1;
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) f.v[t][dt] = ldg4(VTb + (size_t)(hd * DH + 16 * dt + fq) * ldv + (kt << 4) + 4 * g);
     }
   };
   // Mask of chunk c as the INITIAL accumulator of its K Q^T product: 0 where the key is visible, -inf elsewhere
   // (-inf + finite products = -inf).  Computed before the MFMAs are issued, so no VALU work sits between the MFMA
-  // results and the softmax; interior chunks (every key inside the band of every query of the wave and below klim: 3 of
+  // results and the softmax; interior chunks (every key inside the band of every query of the half and below klim: 3 of
   // the 5 chunks at window 64, all of the cross-attention when S % 32 == 0) take the wave-uniform zero path.
-  auto mask_init = [&](int c, f4 (&S)[CH][2]) {
-    c = c < nchunk ? c : nchunk - 1;
-    const int k0 = (kt_lo + c * CH) << 4, k1 = k0 + 16 * CH - 1;
-    bool full = k1 < klim && (kt_lo + (c + 1) * CH) <= kt_hi;
-    if (SELF && window >= 0) full = full && (k1 - m0 <= window) && (k0 - (m0 + kWaveFrames - 1) >= -window);
+  auto mask_init = [&](const Geo& q, int c, f4 (&S)[CH][2]) {
+    c = c < q.nchunk ? c : q.nchunk - 1;
+    const int k0 = (q.kt_lo + c * CH) << 4, k1 = k0 + 16 * CH - 1;
+    bool full = k1 < q.klim && (q.kt_lo + (c + 1) * CH) <= q.kt_hi;
+    if (SELF && window >= 0) full = full && (k1 - q.m0 <= window) && (k0 - (q.m0 + 31) >= -window);
 #pragma unroll
     for (int t = 0; t < CH; ++t) S[t][0] = S[t][1] = splat(0.f);
     if (!full) {
 #pragma unroll
       for (int ft = 0; ft < 2; ++ft) {
-        const int d0 = k0 + 4 * g - (m0 + 16 * ft + fq) - lo_d[ft];  // (key - query - lo_d) of r = 0, tile 0
-        const unsigned sp = span[ft] >= 0 ? (unsigned)span[ft] : 0u;
-        const int bias = span[ft] >= 0 ? 0 : (1 << 30);               // nothing valid for this query
+        const int d0 = k0 + 4 * g - (q.m0 + 16 * ft + fq) - q.lo_d[ft];  // (key - query - lo_d) of r = 0, tile 0
+        const unsigned sp = q.span[ft] >= 0 ? (unsigned)q.span[ft] : 0u;
+        const int bias = q.span[ft] >= 0 ? 0 : (1 << 30);                 // nothing valid for this query
 #pragma unroll
         for (int t = 0; t < CH; ++t)
 #pragma unroll
@@ -380,136 +405,156 @@ EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, cons
     }
   };
 
-  // q fragments (B operand: lane (fq,g) holds q[query][hd*DH + 16a + 4g + b]) and the K fragments of the first two chunks
-  // of a head.  They are fetched while the PREVIOUS head's projection phases run, so no head starts on an exposed load.
+  Geo geo[NHALF];
+#pragma unroll
+  for (int hf = 0; hf < NHALF; ++hf) geo[hf] = make_geo(hf);
+
+  // q fragments (B operand: lane (fq,g) holds q[query][hd*DH + 16a + 4g + b]) and the K / V^T fragments of the first
+  // chunks of a (head, half).  For half 0 they are fetched while the PREVIOUS head's projection phases run, so no head
+  // starts on an exposed load.
   f4 qa_n[2][DFULL > 0 ? DFULL : 1];
   f2 qr_n[2];
   KVFrag<C> KA, KB;
   VFrag<C> VA, VB;
-  auto prefetch_head = [&](int hd) {
+  auto prefetch = [&](const Geo& q, int hd, int half) {
 #pragma unroll
     for (int ft = 0; ft < 2; ++ft) {
 #pragma unroll
-      for (int a = 0; a < DFULL; ++a) qa_n[ft][a] = qload.q4(ft, hd * DH + 16 * a + 4 * g);
-      if (DREM) qr_n[ft] = qload.q2(ft, hd * DH + 16 * DFULL + 2 * g);
+      for (int a = 0; a < DFULL; ++a) qa_n[ft][a] = qload.q4(2 * half + ft, hd * DH + 16 * a + 4 * g);
+      if (DREM) qr_n[ft] = qload.q2(2 * half + ft, hd * DH + 16 * DFULL + 2 * g);
     }
-    load_k(hd, 0, KA);
-    load_k(hd, 1, KB);
-    load_v(hd, 0, VA);
+    load_k(q, hd, 0, KA);
+    load_k(q, hd, 1, KB);
+    load_v(q, hd, 0, VA);
     __builtin_amdgcn_sched_barrier(0);
   };
-  prefetch_head(0);
+  prefetch(geo[0], 0, 0);
 
   for (int hd = 0; hd < C::HEADS; ++hd) {
-    // pre-scale q by log2(e)/sqrt(d): the scores then come out of the MFMA in the exp2 domain
-    f4 qa[2][DFULL > 0 ? DFULL : 1];
-    f2 qr[2];
+    f4 O[DT][NF];
 #pragma unroll
-    for (int ft = 0; ft < 2; ++ft) {
-#pragma unroll
-      for (int a = 0; a < DFULL; ++a) qa[ft][a] = qa_n[ft][a] * c2;
-      if (DREM) qr[ft] = qr_n[ft] * c2;
-    }
-    float mrun[2] = {-1e30f, -1e30f};
-    f4 lvec[2] = {splat(0.f), splat(0.f)};  // per-lane partial row sums (reduced over r and the lane groups at the end)
-    f4 O[DT][2];
-#pragma unroll
-    for (int dt = 0; dt < DT; ++dt) O[dt][0] = O[dt][1] = splat(0.f);
-
-    // One step: finish chunk c (softmax + P V) while the scores of chunk c+1 are produced.
-    //   Sc   : scores of chunk c (complete)          Sn : receives the scores of chunk c+1 (its mask is already in it)
-    //   Kuse : K fragments of chunk c+1 (loaded one step ago)     Kld : receives the K fragments of chunk c+2
-    //   Vuse : V^T fragments of chunk c (loaded one step ago)     Vld : receives the V^T fragments of chunk c+1
-    // Every load is consumed in a LATER step (loop-carried), which is what keeps hipcc from sinking it next to its use:
-    // a V load issued and used within the same step was moved across the rescale branch right in front of the P V MFMAs.
-    // The caller alternates the S / K / V buffers, so nothing is copied between steps.
-    auto step = [&](auto has_next, int c, f4 (&Sc)[CH][2], f4 (&Sn)[CH][2], const KVFrag<C>& Kuse, KVFrag<C>& Kld,
-                    const VFrag<C>& Vuse, VFrag<C>& Vld) {
-      if (decltype(has_next)::value) {
-        load_v(hd, c + 1, Vld);
-        load_k(hd, c + 2, Kld);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      // scores of the NEXT chunk: independent MFMA work that overlaps this chunk's softmax VALU (same scheduling region)
-      if (decltype(has_next)::value) qk(Kuse, qa, qr, Sn);
-      // Online softmax with a DEFERRED running maximum: fp32 accumulators have ~2^127 of headroom, so the reference point
-      // m only has to move when a chunk exceeds it by more than 2^kDefer; until then P = 2^(s - m) <= 2^kDefer and neither O
-      // nor the row sums need rescaling (softmax is invariant to m).  The wave-uniform branch is taken on the first chunk
-      // (m starts at -1e30) and then only when some row's scores jump by > kDefer octaves; it removes the per-chunk
-      // read-modify-write of the O accumulators and the cross-lane max from the common path.
-      float mxl[2];
+    for (int hf = 0; hf < NHALF; ++hf) {
+      const Geo& q = geo[hf];
+      if (hf > 0) prefetch(q, hd, hf);
+      // pre-scale q by log2(e)/sqrt(d): the scores then come out of the MFMA in the exp2 domain
+      f4 qa[2][DFULL > 0 ? DFULL : 1];
+      f2 qr[2];
 #pragma unroll
       for (int ft = 0; ft < 2; ++ft) {
-        f4 mv = Sc[0][ft];
 #pragma unroll
-        for (int t = 1; t < CH; ++t)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) mv[r] = fmaxf(mv[r], Sc[t][ft][r]);
-        mxl[ft] = hmax(mv);
+        for (int a = 0; a < DFULL; ++a) qa[ft][a] = qa_n[ft][a] * c2;
+        if (DREM) qr[ft] = qr_n[ft] * c2;
       }
-      if (__any((mxl[0] > mrun[0] + kDefer) || (mxl[1] > mrun[1] + kDefer))) {
+      float mrun[2] = {-1e30f, -1e30f};
+      f4 lvec[2] = {splat(0.f), splat(0.f)};  // per-lane partial row sums (reduced over r and the lane groups at the end)
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) O[dt][2 * hf] = O[dt][2 * hf + 1] = splat(0.f);
+      const int nchunk = q.nchunk;
+
+      // One step: finish chunk c (softmax + P V) while the scores of chunk c+1 are produced.
+      //   Sc   : scores of chunk c (complete)          Sn : receives the scores of chunk c+1 (its mask is already in it)
+      //   Kuse : K fragments of chunk c+1 (loaded one step ago)     Kld : receives the K fragments of chunk c+2
+      //   Vuse : V^T fragments of chunk c (loaded one step ago)     Vld : receives the V^T fragments of chunk c+1
+      // Every load is consumed in a LATER step (loop-carried), which is what keeps hipcc from sinking it next to its use:
+      // a V load issued and used within the same step was moved across the rescale branch right in front of the P V MFMAs.
+      // The caller alternates the S / K / V buffers, so nothing is copied between steps.
+      auto step = [&](auto has_next, int c, f4 (&Sc)[CH][2], f4 (&Sn)[CH][2], const KVFrag<C>& Kuse, KVFrag<C>& Kld,
+                      const VFrag<C>& Vuse, VFrag<C>& Vld) {
+#ifndef EDTTS_ABLATE_KVLOADS  // timing ablation only
+        if (decltype(has_next)::value) {
+          load_v(q, hd, c + 1, Vld);
+          load_k(q, hd, c + 2, Kld);
+        }
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+        // scores of the NEXT chunk: independent MFMA work that overlaps this chunk's softmax VALU (same scheduling region)
+        if (decltype(has_next)::value) qk(Kuse, qa, qr, Sn);
+#ifdef EDTTS_ABLATE_SOFTMAX  // timing ablation only: P = S (no max, no exp, no rescale); results are wrong by construction
+        f4 P[CH][2];
+#pragma unroll
+        for (int t = 0; t < CH; ++t) { P[t][0] = Sc[t][0]; P[t][1] = Sc[t][1]; lvec[0] += Sc[t][0]; }
+#else
+        // Online softmax with a DEFERRED running maximum: fp32 accumulators have ~2^127 of headroom, so the reference point
+        // m only has to move when a chunk exceeds it by more than 2^kDefer; until then P = 2^(s - m) <= 2^kDefer and neither O
+        // nor the row sums need rescaling (softmax is invariant to m).  The wave-uniform branch is taken on the first chunk
+        // (m starts at -1e30) and then only when some row's scores jump by > kDefer octaves; it removes the per-chunk
+        // read-modify-write of the O accumulators and the cross-lane max from the common path.
+        float mxl[2];
 #pragma unroll
         for (int ft = 0; ft < 2; ++ft) {
-          const float mnew = fmaxf(mrun[ft], group_max(mxl[ft]));  // identical on the 4 lanes of a row
-          const float alpha = fast_exp2(mrun[ft] - mnew);           // mrun starts finite (-1e30): never NaN
-          mrun[ft] = mnew;
-          lvec[ft] *= alpha;
+          f4 mv = Sc[0][ft];
 #pragma unroll
-          for (int dt = 0; dt < DT; ++dt) O[dt][ft] *= alpha;
+          for (int t = 1; t < CH; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mv[r] = fmaxf(mv[r], Sc[t][ft][r]);
+          mxl[ft] = hmax(mv);
         }
+        if (__any((mxl[0] > mrun[0] + kDefer) || (mxl[1] > mrun[1] + kDefer))) {
+#pragma unroll
+          for (int ft = 0; ft < 2; ++ft) {
+            const float mnew = fmaxf(mrun[ft], group_max(mxl[ft]));  // identical on the 4 lanes of a row
+            const float alpha = fast_exp2(mrun[ft] - mnew);           // mrun starts finite (-1e30): never NaN
+            mrun[ft] = mnew;
+            lvec[ft] *= alpha;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) O[dt][2 * hf + ft] *= alpha;
+          }
+        }
+        f4 P[CH][2];
+#pragma unroll
+        for (int ft = 0; ft < 2; ++ft) {
+#pragma unroll
+          for (int t = 0; t < CH; ++t) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) P[t][ft][r] = fast_exp2(Sc[t][ft][r] - mrun[ft]);
+            lvec[ft] += P[t][ft];
+          }
+        }
+#endif
+        // O^T += V^T P^T : DT x 2 independent accumulators, r outermost
+#pragma unroll
+        for (int t = 0; t < CH; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+              O[dt][2 * hf] = EDTTS_MFMA(Vuse.v[t][dt][r], P[t][0][r], O[dt][2 * hf]);
+              O[dt][2 * hf + 1] = EDTTS_MFMA(Vuse.v[t][dt][r], P[t][1][r], O[dt][2 * hf + 1]);
+            }
+      };
+
+      f4 SA[CH][2], SB[CH][2];
+      mask_init(q, 0, SA);
+      qk(KA, qa, qr, SA);  // scores of chunk 0; KB holds chunk 1, VA chunk 0
+      using Yes = std::integral_constant<bool, true>;
+      using No = std::integral_constant<bool, false>;
+      int c = 0;
+      for (; c + 2 < nchunk; c += 2) {
+        mask_init(q, c + 1, SB);
+        step(Yes{}, c, SA, SB, KB, KA, VA, VB);      // finishes chunk c; scores of c+1 -> SB (from KB); loads K(c+2) -> KA, V(c+1) -> VB
+        mask_init(q, c + 2, SA);
+        step(Yes{}, c + 1, SB, SA, KA, KB, VB, VA);  // finishes chunk c+1; scores of c+2 -> SA (from KA); loads K(c+3) -> KB, V(c+2) -> VA
       }
-      f4 P[CH][2];
+      if (nchunk - c == 2) {  // two chunks left: scores of c are in SA, V(c) in VA
+        mask_init(q, c + 1, SB);
+        step(Yes{}, c, SA, SB, KB, KA, VA, VB);
+        step(No{}, c + 1, SB, SA, KA, KB, VB, VA);
+      } else {                // one chunk left
+        step(No{}, c, SA, SB, KB, KA, VA, VB);
+      }
+      // normalise this half's rows
 #pragma unroll
       for (int ft = 0; ft < 2; ++ft) {
+        const float lt = group_sum(hsum(lvec[ft]));
+        const float inv = lt > 0.f ? 1.0f / lt : 0.f;
 #pragma unroll
-        for (int t = 0; t < CH; ++t) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) P[t][ft][r] = fast_exp2(Sc[t][ft][r] - mrun[ft]);
-          lvec[ft] += P[t][ft];
-        }
+        for (int dt = 0; dt < DT; ++dt) O[dt][2 * hf + ft] *= inv;
       }
-      // O^T += V^T P^T : DT x 2 independent accumulators, r outermost
-#pragma unroll
-      for (int t = 0; t < CH; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-          for (int dt = 0; dt < DT; ++dt) {
-            O[dt][0] = EDTTS_MFMA(Vuse.v[t][dt][r], P[t][0][r], O[dt][0]);
-            O[dt][1] = EDTTS_MFMA(Vuse.v[t][dt][r], P[t][1][r], O[dt][1]);
-          }
-    };
-
-    f4 SA[CH][2], SB[CH][2];
-    mask_init(0, SA);
-    qk(KA, qa, qr, SA);  // scores of chunk 0; KB holds chunk 1
-    using Yes = std::integral_constant<bool, true>;
-    using No = std::integral_constant<bool, false>;
-    int c = 0;
-    for (; c + 2 < nchunk; c += 2) {
-      mask_init(c + 1, SB);
-      step(Yes{}, c, SA, SB, KB, KA, VA, VB);      // finishes chunk c; scores of c+1 -> SB (from KB); loads K(c+2) -> KA, V(c+1) -> VB
-      mask_init(c + 2, SA);
-      step(Yes{}, c + 1, SB, SA, KA, KB, VB, VA);  // finishes chunk c+1; scores of c+2 -> SA (from KA); loads K(c+3) -> KB, V(c+2) -> VA
     }
-    if (nchunk - c == 2) {  // two chunks left: scores of c are in SA, V(c) in VA
-      mask_init(c + 1, SB);
-      step(Yes{}, c, SA, SB, KB, KA, VA, VB);
-      step(No{}, c + 1, SB, SA, KA, KB, VB, VA);
-    } else {                // one chunk left
-      step(No{}, c, SA, SB, KB, KA, VA, VB);
-    }
-    // ---- normalise and project: h[nt] += Wo[:, head features] . O ------------------------------------------
+    // ---- project: h[nt] += Wo[:, head features] . O  (all NF frame tiles at once) ------------------------------------
+    if (hd + 1 < C::HEADS) prefetch(geo[0], hd + 1, 0);
 #pragma unroll
-    for (int ft = 0; ft < 2; ++ft) {
-      const float lt = group_sum(hsum(lvec[ft]));
-      const float inv = lt > 0.f ? 1.0f / lt : 0.f;
-#pragma unroll
-      for (int dt = 0; dt < DT; ++dt) O[dt][ft] *= inv;
-    }
-    if (hd + 1 < C::HEADS) prefetch_head(hd + 1);
-#pragma unroll
-    for (int dt = 0; dt < DT; ++dt) ktile_phase<C::HT>(ring, O[dt][0], O[dt][1], h);
+    for (int dt = 0; dt < DT; ++dt) ktile_phase<C::HT>(ring, O[dt], h);
   }
 }
 

@@ -323,15 +323,15 @@ struct TileId {
   bool valid;  // false: a padding wave of the last block -- it recomputes the last tile (keeps the block's barriers
                // balanced) and must not store anything
 };
-EDTTS_DEV TileId wave_tile(int B, int Tp, int waves_per_block) {
+EDTTS_DEV TileId wave_tile(int B, int Tp, int waves_per_block, int wave_frames) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int tpu = Tp / kWaveFrames;
+  const int tpu = Tp / wave_frames;
   int w = remap_block(blockIdx.x, gridDim.x) * waves_per_block + wave;
   TileId t;
   t.valid = w < B * tpu;
   w = t.valid ? w : B * tpu - 1;
   t.b = w / tpu;
-  t.m0 = (w - t.b * tpu) * kWaveFrames;
+  t.m0 = (w - t.b * tpu) * wave_frames;
   return t;
 }
 
@@ -340,25 +340,27 @@ EDTTS_DEV TileId wave_tile(int B, int Tp, int waves_per_block) {
 // (layers/attention.py:91-93: rows of qkv.weight are q | k | v, each head-major)
 // ---------------------------------------------------------------------------------------------------------
 template <class C>
-EDTTS_DEV void qkv_tail(WStream<C>& ring, const f4 (&hn)[C::HT][2], const KArgs& a, int b, int m0, int lane, bool valid) {
+EDTTS_DEV void qkv_tail(WStream<C>& ring, const f4 (&hn)[C::HT][C::NF], const KArgs& a, int b, int m0, int lane, bool valid) {
+  constexpr int NF = C::NF;
   const int fq = lane & 15, g = lane >> 4;
   const size_t rowbase = (size_t)b * a.Tp + m0 + fq;
   for (int which = 0; which < 3; ++which) {
     for (int nt = 0; nt < C::HT; ++nt) {
-      f4 a0 = splat(0.f), a1 = splat(0.f);
-      gemm_phase<C::HT>(ring, hn, a0, a1);
+      f4 acc[NF];
+#pragma unroll
+      for (int ft = 0; ft < NF; ++ft) acc[ft] = splat(0.f);
+      gemm_phase<C::HT>(ring, hn, acc);
       if (!valid) continue;
       if (which < 2) {
         float* dst = (which == 0 ? a.q : a.k) + rowbase * C::H + 16 * nt + 4 * g;
-        stg4(dst, a0);
-        stg4(dst + 16 * C::H, a1);
+#pragma unroll
+        for (int ft = 0; ft < NF; ++ft) stg4(dst + (size_t)ft * 16 * C::H, acc[ft]);
       } else {
         float* dst = a.vT + ((size_t)b * C::VR + 16 * nt + 4 * g) * a.Tp + m0 + fq;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          dst[(size_t)r * a.Tp] = a0[r];
-          dst[(size_t)r * a.Tp + 16] = a1[r];
-        }
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int ft = 0; ft < NF; ++ft) dst[(size_t)r * a.Tp + 16 * ft] = acc[ft][r];
       }
     }
   }
@@ -369,28 +371,27 @@ EDTTS_DEV void qkv_tail(WStream<C>& ring, const f4 (&hn)[C::HT][2], const KArgs&
 // =========================================================================================================
 template <class C>
 __global__ __launch_bounds__(C::THREADS) void k_prologue(KArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const TileId tl = wave_tile(a.B, a.Tp, C::WAVES);
+  constexpr int NF = C::NF;
+  const TileId tl = wave_tile(a.B, a.Tp, C::WAVES, C::WF);
   const int lane = threadIdx.x & 63, fq = lane & 15, g = lane >> 4;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int b = tl.b, m0 = tl.m0;
   WStream<C> ring;
   ring.prime(a.stream, lane);
-  f4 xin[C::MT][2];
+  f4 xin[C::MT][NF];
 #pragma unroll
-  for (int ft = 0; ft < 2; ++ft) {
+  for (int ft = 0; ft < NF; ++ft) {
     const int f = m0 + 16 * ft + fq;
 #pragma unroll
     for (int t = 0; t < C::MT; ++t)
       xin[t][ft] = f < a.T ? ldg4(a.x + ((size_t)b * a.T + f) * C::MEL + 16 * t + 4 * g) : splat(0.f);
   }
-  f4 h[C::HT][2];
+  f4 h[C::HT][NF];
   const f4* wp = reinterpret_cast<const f4*>(a.inp) + lane;
 #pragma unroll
   for (int nt = 0; nt < C::HT; ++nt) {
     const f4 bias = ldg4(a.inp_b + 16 * nt + 4 * g);
 #pragma unroll
-    for (int ft = 0; ft < 2; ++ft) {
+    for (int ft = 0; ft < NF; ++ft) {
       int f = m0 + 16 * ft + fq;
       f = f < a.max_pos ? f : a.max_pos - 1;
       h[nt][ft] = bias + ldg4(a.pe + (size_t)f * C::H + 16 * nt + 4 * g);  // embeddings.py:142
@@ -399,23 +400,21 @@ __global__ __launch_bounds__(C::THREADS) void k_prologue(KArgs a) {
     for (int kt = 0; kt < C::MT; ++kt) {
       const f4 w = wp[(nt * C::MT + kt) * 64];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        h[nt][0] = EDTTS_MFMA(w[r], xin[kt][0][r], h[nt][0]);
-        h[nt][1] = EDTTS_MFMA(w[r], xin[kt][1][r], h[nt][1]);
-      }
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int ft = 0; ft < NF; ++ft) h[nt][ft] = EDTTS_MFMA(w[r], xin[kt][ft][r], h[nt][ft]);
     }
   }
   if (tl.valid) {
     float* hp = a.h + ((size_t)b * a.Tp + m0 + fq) * C::H + 4 * g;
 #pragma unroll
-    for (int nt = 0; nt < C::HT; ++nt) {
-      stg4(hp + 16 * nt, h[nt][0]);
-      stg4(hp + 16 * nt + 16 * C::H, h[nt][1]);
-    }
+    for (int nt = 0; nt < C::HT; ++nt)
+#pragma unroll
+      for (int ft = 0; ft < NF; ++ft) stg4(hp + 16 * nt + (size_t)ft * 16 * C::H, h[nt][ft]);
   }
-  f4 hn[C::HT][2];
+  f4 hn[C::HT][NF];
   const float* mod = a.cond + (size_t)b * a.cond_bstride;  // layer 0, norm1
-  rms_norm_tile<C::HT>(h, a.n1w, mod, g, hn);
+  rms_norm_tile<C::HT, NF>(h, a.n1w, mod, g, hn);
   qkv_tail<C>(ring, hn, a, b, m0, lane, tl.valid);
 }
 
@@ -425,7 +424,7 @@ __global__ __launch_bounds__(C::THREADS) void k_prologue(KArgs a) {
 enum { TAIL_QKV = 0, TAIL_EPS = 1, TAIL_DDIM = 2 };
 
 struct QGlobal {  // q rows in global memory, row-major [Tp][H]
-  const float* base;  // row of query frame (ft = 0, fq)
+  const float* base;  // row of query frame (frame tile 0, fq)
   int H;
   EDTTS_DEV f4 q4(int ft, int col) const { return ldg4(base + (size_t)ft * 16 * H + col); }
   EDTTS_DEV f2 q2(int ft, int col) const { return ldg2(base + (size_t)ft * 16 * H + col); }
@@ -440,25 +439,26 @@ struct QLds {  // q tile in this wave's LDS region, [32][QLD]
 template <class C, int TAIL>
 __global__ __launch_bounds__(C::THREADS) void k_layer(KArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const TileId tl = wave_tile(a.B, a.Tp, C::WAVES);
+  constexpr int NF = C::NF;
+  const TileId tl = wave_tile(a.B, a.Tp, C::WAVES, C::WF);
   const int lane = threadIdx.x & 63, fq = lane & 15, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int b = tl.b, m0 = tl.m0;
-  float* qtile = smem + (size_t)wave * kWaveFrames * C::QLD;
+  float* qtile = smem + (size_t)wave * C::WF * C::QLD;
   const size_t rowbase = (size_t)b * a.Tp + m0 + fq;
 
   WStream<C> ring;
   ring.prime(a.stream, lane);
 
   // residual stream tile, + self-attention projection bias (attention.py:123)
-  f4 h[C::HT][2];
+  f4 h[C::HT][NF];
   {
     const float* hp = a.h + rowbase * C::H + 4 * g;
 #pragma unroll
     for (int nt = 0; nt < C::HT; ++nt) {
       const f4 pb = ldg4(a.proj_b + 16 * nt + 4 * g);
-      h[nt][0] = ldg4(hp + 16 * nt) + pb;
-      h[nt][1] = ldg4(hp + 16 * nt + 16 * C::H) + pb;
+#pragma unroll
+      for (int ft = 0; ft < NF; ++ft) h[nt][ft] = ldg4(hp + 16 * nt + (size_t)ft * 16 * C::H) + pb;
     }
   }
 #ifdef EDTTS_DIAG
@@ -474,13 +474,15 @@ __global__ __launch_bounds__(C::THREADS) void k_layer(KArgs a) {
   }
   // ---- x = x + cross_attn(norm2(x), context)   (transformer.py:151, mla.py:118-194) --------------------------
   if (DIAG_ON(2)) {
-    f4 hn[C::HT][2];
-    rms_norm_tile<C::HT>(h, a.n2w, nullptr, g, hn);
+    f4 hn[C::HT][NF];
+    rms_norm_tile<C::HT, NF>(h, a.n2w, nullptr, g, hn);
     for (int nt = 0; nt < C::HT; ++nt) {
-      f4 a0 = splat(0.f), a1 = splat(0.f);
-      gemm_phase<C::HT>(ring, hn, a0, a1);
-      stg4(qtile + fq * C::QLD + 16 * nt + 4 * g, a0);
-      stg4(qtile + (16 + fq) * C::QLD + 16 * nt + 4 * g, a1);
+      f4 acc[NF];
+#pragma unroll
+      for (int ft = 0; ft < NF; ++ft) acc[ft] = splat(0.f);
+      gemm_phase<C::HT>(ring, hn, acc);
+#pragma unroll
+      for (int ft = 0; ft < NF; ++ft) stg4(qtile + (16 * ft + fq) * C::QLD + 16 * nt + 4 * g, acc[ft]);
     }
   }
   if (DIAG_ON(2)) {
@@ -490,27 +492,29 @@ __global__ __launch_bounds__(C::THREADS) void k_layer(KArgs a) {
   }
   // ---- x = x + ffn(norm3(x, cond))   (transformer.py:154-158, :13-49) ----------------------------------------
   if (DIAG_ON(4)) {
-    f4 hn[C::HT][2];
+    f4 hn[C::HT][NF];
     const float* mod = a.cond + (size_t)b * a.cond_bstride + ((size_t)a.layer * 2 + 1) * 2 * C::H;
-    rms_norm_tile<C::HT>(h, a.n3w, mod, g, hn);
+    rms_norm_tile<C::HT, NF>(h, a.n3w, mod, g, hn);
 #pragma unroll
     for (int nt = 0; nt < C::HT; ++nt) {
       const f4 db = ldg4(a.down_b + 16 * nt + 4 * g);
-      h[nt][0] += db;
-      h[nt][1] += db;
+#pragma unroll
+      for (int ft = 0; ft < NF; ++ft) h[nt][ft] += db;
     }
     for (int j = 0; j < 2 * C::HT; ++j) {
       const f4 vb = ldg4(a.up_b + 32 * j + 4 * g), gb = ldg4(a.up_b + 32 * j + 16 + 4 * g);
-      f4 v0 = splat(0.f), v1 = splat(0.f), g0 = splat(0.f), g1 = splat(0.f);
-      gemm_phase_pair<C::HT>(ring, hn, v0, v1, g0, g1);
-      v0 += vb; v1 += vb; g0 += gb; g1 += gb;  // bias after the GEMM: its load is off the MFMA critical path
-      f4 act0, act1;
+      f4 v[NF], gt[NF], act[NF];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        act0[r] = v0[r] * silu(g0[r]);  // SwiGLU: value * silu(gate), transformer.py:21-23
-        act1[r] = v1[r] * silu(g1[r]);
+      for (int ft = 0; ft < NF; ++ft) v[ft] = gt[ft] = splat(0.f);
+      gemm_phase_pair<C::HT>(ring, hn, v, gt);
+#pragma unroll
+      for (int ft = 0; ft < NF; ++ft) {
+        v[ft] += vb;  // bias after the GEMM: its load is off the MFMA critical path
+        gt[ft] += gb;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) act[ft][r] = v[ft][r] * silu(gt[ft][r]);  // SwiGLU: value * silu(gate), transformer.py:21-23
       }
-      ktile_phase<C::HT>(ring, act0, act1, h);
+      ktile_phase<C::HT>(ring, act, h);
     }
   }
   // ---- tail ---------------------------------------------------------------------------------------------------
@@ -519,32 +523,32 @@ __global__ __launch_bounds__(C::THREADS) void k_layer(KArgs a) {
     if (tl.valid) {
       float* hp = a.h + rowbase * C::H + 4 * g;
 #pragma unroll
-      for (int nt = 0; nt < C::HT; ++nt) {
-        stg4(hp + 16 * nt, h[nt][0]);
-        stg4(hp + 16 * nt + 16 * C::H, h[nt][1]);
-      }
+      for (int nt = 0; nt < C::HT; ++nt)
+#pragma unroll
+        for (int ft = 0; ft < NF; ++ft) stg4(hp + 16 * nt + (size_t)ft * 16 * C::H, h[nt][ft]);
     }
-    f4 hn[C::HT][2];
+    f4 hn[C::HT][NF];
     const float* mod = a.cond + (size_t)b * a.cond_bstride + ((size_t)(a.layer + 1) * 2) * 2 * C::H;
-    rms_norm_tile<C::HT>(h, a.n1w, mod, g, hn);
+    rms_norm_tile<C::HT, NF>(h, a.n1w, mod, g, hn);
     qkv_tail<C>(ring, hn, a, b, m0, lane, tl.valid);
   } else {
-    f4 hn[C::HT][2];
-    layer_norm_tile<C::HT>(h, a.fnw, a.fnb, g, hn);
+    f4 hn[C::HT][NF];
+    layer_norm_tile<C::HT, NF>(h, a.fnw, a.fnb, g, hn);
 #pragma unroll
     for (int nt = 0; nt < C::MT; ++nt) {
       const f4 ob = ldg4(a.outp_b + 16 * nt + 4 * g);
-      f4 e0 = splat(0.f), e1 = splat(0.f);
-      gemm_phase<C::HT>(ring, hn, e0, e1);
-      e0 += ob; e1 += ob;
+      f4 e[NF];
 #pragma unroll
-      for (int ft = 0; ft < 2; ++ft) {
+      for (int ft = 0; ft < NF; ++ft) e[ft] = splat(0.f);
+      gemm_phase<C::HT>(ring, hn, e);
+#pragma unroll
+      for (int ft = 0; ft < NF; ++ft) {
         const int f = m0 + 16 * ft + fq;
         if (f >= a.T || !tl.valid) continue;
         const size_t idx = ((size_t)b * a.T + f) * C::MEL + 16 * nt + 4 * g;
-        const f4 e = ft ? e1 : e0;
+        const f4 ev = e[ft] + ob;
         if (TAIL == TAIL_EPS) {
-          stg4(a.eps + idx, e);
+          stg4(a.eps + idx, ev);
         } else {
           // DDIM update, same operation order as schedule.py:189-199 (no fma contraction)
           const f4 xv = ldg4(a.x + idx);
@@ -552,7 +556,7 @@ __global__ __launch_bounds__(C::THREADS) void k_layer(KArgs a) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             float v0, vp;
-            ddim_elem(xv[r], e[r], a.c_s1m, a.c_sab, a.c_sabp, a.c_dir, v0, vp);
+            ddim_elem(xv[r], ev[r], a.c_s1m, a.c_sab, a.c_sabp, a.c_dir, v0, vp);
             x0[r] = v0;
             xp[r] = vp;
           }
@@ -576,9 +580,9 @@ struct CtxArgs {
   unsigned kvd[kMaxLayers], kvn[kMaxLayers], kvu[kMaxLayers];
   float *kc, *vcT;  // [L][B][Sp][H], [L][B][VR][Sp]
 };
-template <class C>
+template <class C>  // always instantiated with NF = 2 (32 context tokens per wave)
 __global__ __launch_bounds__(64 * kCtxWaves) void k_ctx(CtxArgs a) {
-  const TileId tl = wave_tile(a.B, a.Sp, kCtxWaves);
+  const TileId tl = wave_tile(a.B, a.Sp, kCtxWaves, 32);
   if (!tl.valid) return;  // no block-level synchronisation in this kernel
   const int lane = threadIdx.x & 63, fq = lane & 15, g = lane >> 4;
   const int b = tl.b, m0 = tl.m0;
@@ -634,28 +638,28 @@ __global__ __launch_bounds__(64 * kCtxWaves) void k_ctx(CtxArgs a) {
 #pragma unroll
       for (int nt = 0; nt < C::RT; ++nt) {
         c[nt][0] = c[nt][1] = splat(0.f);
-        gemm_phase<C::HT>(ring, ctx, c[nt][0], c[nt][1]);
+        gemm_phase<C::HT>(ring, ctx, c[nt]);
       }
     }
     f4 cn[C::RT][2];
-    rms_norm_tile<C::RT>(c, a.blob + a.kvn[l], nullptr, g, cn);
+    rms_norm_tile<C::RT, 2>(c, a.blob + a.kvn[l], nullptr, g, cn);
     // kv = kv_up(c): first H outputs = K, second H = V   (mla.py:150-153)
     FragRing<C::RT> ring;
     ring.prime(a.blob + a.kvu[l], lane);
     float* kdst = a.kc + (((size_t)l * a.B + b) * a.Sp + m0 + fq) * C::H + 4 * g;
     float* vdst = a.vcT + (((size_t)l * a.B + b) * C::VR + 4 * g) * a.Sp + m0 + fq;
     for (int nt = 0; nt < 2 * C::HT; ++nt) {
-      f4 a0 = splat(0.f), a1 = splat(0.f);
-      gemm_phase<C::RT>(ring, cn, a0, a1);
+      f4 acc[2] = {splat(0.f), splat(0.f)};
+      gemm_phase<C::RT>(ring, cn, acc);
       if (nt < C::HT) {
-        stg4(kdst + 16 * nt, a0);
-        stg4(kdst + 16 * nt + 16 * C::H, a1);
+        stg4(kdst + 16 * nt, acc[0]);
+        stg4(kdst + 16 * nt + 16 * C::H, acc[1]);
       } else {
         float* d = vdst + (size_t)(16 * (nt - C::HT)) * a.Sp;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          d[(size_t)r * a.Sp] = a0[r];
-          d[(size_t)r * a.Sp + 16] = a1[r];
+          d[(size_t)r * a.Sp] = acc[0][r];
+          d[(size_t)r * a.Sp + 16] = acc[1][r];
         }
       }
     }
@@ -803,10 +807,20 @@ struct Workspace {
   size_t h, q, k, vT, kc, vcT, cond, total;  // offsets in floats
   int Tp, Sp, VR;
 };
+// frame tiles per wave of the default-decoder instance.  Measured (B=256, T=512): NF=4 lifts the FFN phase from 80 % to 88 %
+// MFMA-busy as the bare-stream probe predicts, but the attention phases lose more under the doubled register footprint
+// (hipcc spills / shuffles AGPRs): k_layer 1.105 ms vs 1.046 ms at NF=2.  -DEDTTS_NF_DEFAULT=4 builds the 64-frame variant.
+#ifndef EDTTS_NF_DEFAULT
+#define EDTTS_NF_DEFAULT 2
+#endif
+// frames per wave of the kernel instance that serves these dims (must mirror EDTTS_DISPATCH)
+static int wave_frames(const Layout& lo) { return (lo.H == 160 && lo.HEADS == 4 && lo.MEL == 80) ? 16 * EDTTS_NF_DEFAULT : 32; }
+
 static void make_workspace(const Layout& lo, int B, int T, int S, int cond_rows, Workspace* w) {
   const size_t H = lo.H;
-  w->Tp = (T + kWaveFrames - 1) / kWaveFrames * kWaveFrames;
-  w->Sp = (S + kWaveFrames - 1) / kWaveFrames * kWaveFrames;
+  const int wf = wave_frames(lo);
+  w->Tp = (T + wf - 1) / wf * wf;
+  w->Sp = (S + 31) / 32 * 32;
   w->VR = (lo.HEADS - 1) * lo.DH + lo.DHP;
   size_t o = 0;
   auto take = [&](size_t n) { size_t r = o; o = align64(o + n); return r; };
@@ -823,9 +837,10 @@ static void make_workspace(const Layout& lo, int B, int T, int S, int cond_rows,
 template <class C>
 struct Launcher {
   static size_t ring_lds() { return 0; }
-  static size_t layer_lds() { return ring_lds() + (size_t)C::WAVES * kWaveFrames * C::QLD * sizeof(float); }
-  static int grid(int B, int Tp) { return (B * (Tp / kWaveFrames) + C::WAVES - 1) / C::WAVES; }
-  static int ctx_grid(int B, int Sp) { return (B * (Sp / kWaveFrames) + kCtxWaves - 1) / kCtxWaves; }
+  static size_t layer_lds() { return ring_lds() + (size_t)C::WAVES * C::WF * C::QLD * sizeof(float); }
+  static int grid(int B, int Tp) { return (B * (Tp / C::WF) + C::WAVES - 1) / C::WAVES; }
+  static int ctx_grid(int B, int Sp) { return (B * (Sp / 32) + kCtxWaves - 1) / kCtxWaves; }
+  using C2 = Cfg<C::H, C::HEADS, C::MEL, 2>;  // geometry of the context kernel
 
   static int ctx(const Layout& lo, const float* blob, const Workspace& ws, float* wsb, int B, int S, const int64_t* sem_idx,
                  const float* sem_feat, hipStream_t st) {
@@ -838,7 +853,7 @@ struct Launcher {
       a.kvd[l] = (unsigned)lo.layer[l].kvd; a.kvn[l] = (unsigned)lo.layer[l].kvn; a.kvu[l] = (unsigned)lo.layer[l].kvu;
     }
     a.kc = wsb + ws.kc; a.vcT = wsb + ws.vcT;
-    hipLaunchKernelGGL(k_ctx<C>, dim3(ctx_grid(B, ws.Sp)), dim3(64 * kCtxWaves), 0, st, a);
+    hipLaunchKernelGGL(k_ctx<C2>, dim3(ctx_grid(B, ws.Sp)), dim3(64 * kCtxWaves), 0, st, a);
     LAUNCH_CHECK("k_ctx");
     return EDTTS_OK;
   }
@@ -907,7 +922,7 @@ struct Launcher {
 // compiled decoder shapes: (hidden, heads, n_mels)
 #define EDTTS_DISPATCH(lo, CALL)                                                                         \
   do {                                                                                                   \
-    if ((lo).H == 160 && (lo).HEADS == 4 && (lo).MEL == 80) { using C = Cfg<160, 4, 80>; CALL; }          \
+    if ((lo).H == 160 && (lo).HEADS == 4 && (lo).MEL == 80) { using C = Cfg<160, 4, 80, EDTTS_NF_DEFAULT>; CALL; } \
     else if ((lo).H == 256 && (lo).HEADS == 8 && (lo).MEL == 80) { using C = Cfg<256, 8, 80>; CALL; }     \
     else if ((lo).H == 32 && (lo).HEADS == 2 && (lo).MEL == 80) { using C = Cfg<32, 2, 80>; CALL; }       \
     else if ((lo).H == 64 && (lo).HEADS == 4 && (lo).MEL == 16) { using C = Cfg<64, 4, 16>; CALL; }       \
