@@ -172,7 +172,9 @@ def cpu_baseline(cfg, sd, Bc, T):
     """The CPU oracle (a PyTorch-CPU port of the reference path, validated against the reference's outputs in
     tests/test_oracle_vs_golden.py) timed on this host: one 4-step generate_mel on a bounded sample."""
     from oracle import edtts_oracle as O
-    threads = torch.get_num_threads()
+    # this process's CPU share on the GPU box is 16 cores (torch would otherwise start one thread per host core)
+    threads = int(os.environ.get("EDTTS_CPU_THREADS", str(min(16, os.cpu_count() or 1))))
+    torch.set_num_threads(threads)
     S = T // 2
     g = torch.Generator().manual_seed(2)
     sem = torch.randint(0, cfg.codebook_size, (Bc, S), generator=g)
