@@ -61,13 +61,14 @@ def main():
             raise SystemExit("--gpus N > 1 must be launched with `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`")
         raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
     import __graft_entry__
-    if rank == 0:
-        __graft_entry__.build()
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if rank == 0:
+        __graft_entry__.build()  # (re)build the HIP library once; the other ranks load it after the barrier
+    if world > 1:
         dist.barrier()
     dev = torch.device("cuda", local_rank if world > 1 else 0)
     torch.cuda.set_device(dev)
@@ -99,7 +100,8 @@ def main():
     for _ in range(args.warmup):
         step()
     n_layer_launches = args.steps * 4 * cfg.layers
-    if world == 1:
+    profile = world == 1 and os.environ.get("EDTTS_BENCH_NO_EVENTS", "0") != "1"
+    if profile:
         native.profile_enable(n_layer_launches)
     torch.cuda.synchronize(dev)
     if world > 1:
@@ -132,7 +134,9 @@ def main():
         "mels_per_s": world * B / (dt / args.steps),
     }
 
-    if world == 1:
+    if world == 1 and not profile:
+        result["note"] = "EDTTS_BENCH_NO_EVENTS=1: roofline leg skipped"
+    if profile:
         layer_ms, n = native.profile_collect()
         native.profile_enable(0)
         frames = B * T

@@ -291,3 +291,72 @@ def test_forward_large_score_range():
     print(f"large-score-range forward: ours vs fp64 {ours:.2e}, oracle fp32 vs fp64 {theirs:.2e}")
     assert bool(torch.isfinite(e).all())
     assert ours < max(5e-4, 20 * theirs)
+
+
+@pytest.mark.parametrize("B,S", [(1, 1), (3, 7), (5, 16), (2, 100)])
+def test_forward_small_and_odd_shapes(B, S):
+    """Shortest possible utterance (S=1 -> T=2), lengths that are not multiples of any tile, odd batches."""
+    cfg = CFG(device=DEV)
+    dec = make_decoder(cfg, 0)
+    sd = synth_state_dict(cfg, 0)
+    gen = torch.Generator().manual_seed(100 + S)
+    T = 2 * S
+    x = torch.randn(B, T, 80, generator=gen)
+    sem = torch.randint(0, 512, (B, S), generator=gen)
+    t = torch.randint(0, 1000, (B,), generator=gen)
+    si = torch.randint(0, 16, (B,), generator=gen)
+    e = dec(cu(x), cu(t), cu(sem), cu(si)).cpu()
+    assert max_abs(e, O.decoder_forward(sd, x, t, sem, si)) < FWD_TOL
+
+
+def test_forward_maximum_lengths():
+    """T = 1000 and S = 500 (the reference's positional tables hold 1000 / 512 rows), max token id, max step index."""
+    cfg = CFG(device=DEV)
+    dec = make_decoder(cfg, 0)
+    sd = synth_state_dict(cfg, 0)
+    gen = torch.Generator().manual_seed(77)
+    x = torch.randn(1, 1000, 80, generator=gen)
+    sem = torch.randint(0, 512, (1, 500), generator=gen)
+    sem[0, :3] = 511
+    t, si = torch.tensor([999]), torch.tensor([15])
+    e = dec(cu(x), cu(t), cu(sem), cu(si)).cpu()
+    assert max_abs(e, O.decoder_forward(sd, x, t, sem, si)) < FWD_TOL
+    # S = 512 is the context table's limit; T stays below 1000 by passing a shorter x than 2*S would give
+    sem2 = torch.randint(0, 512, (1, 512), generator=gen)
+    x2 = torch.randn(1, 96, 80, generator=gen)
+    e2 = dec(cu(x2), cu(t), cu(sem2), cu(si)).cpu()
+    assert max_abs(e2, O.decoder_forward(sd, x2, t, sem2, si)) < FWD_TOL
+
+
+def test_forward_full_attention_and_other_windows():
+    """attn_window_size=None (full self-attention, layers/attention.py:94) and windows that are not multiples of the key tile."""
+    for window in (None, 5, 37, 200):
+        cfg = CFG(device=DEV, attn_window_size=window)
+        dec = make_decoder(cfg, 2)
+        sd = synth_state_dict(cfg, 2)
+        gen = torch.Generator().manual_seed(5)
+        B, S = 2, 60
+        x = torch.randn(B, 2 * S, 80, generator=gen)
+        sem = torch.randint(0, 512, (B, S), generator=gen)
+        t, si = torch.tensor([400, 3]), torch.tensor([2, 9])
+        e = dec(cu(x), cu(t), cu(sem), cu(si)).cpu()
+        assert max_abs(e, O.decoder_forward(sd, x, t, sem, si, window=window)) < FWD_TOL, window
+
+
+def test_weights_repacked_after_update():
+    """Parameter changes (load_state_dict / in-place edits) must reach the packed blob."""
+    cfg = CFG(device=DEV)
+    dec = make_decoder(cfg, 0)
+    gen = torch.Generator().manual_seed(8)
+    x = torch.randn(1, 64, 80, generator=gen)
+    sem = torch.randint(0, 512, (1, 32), generator=gen)
+    t, si = torch.tensor([500]), torch.tensor([1])
+    e0 = dec(cu(x), cu(t), cu(sem), cu(si)).cpu()
+    sd1 = synth_state_dict(cfg, 1)
+    dec.load_state_dict(sd1)
+    e1 = dec(cu(x), cu(t), cu(sem), cu(si)).cpu()
+    assert max_abs(e1, O.decoder_forward(sd1, x, t, sem, si)) < FWD_TOL and max_abs(e0, e1) > 1e-2
+    with torch.no_grad():
+        dec.out_proj.bias.add_(1.0)
+    e2 = dec(cu(x), cu(t), cu(sem), cu(si)).cpu()
+    assert max_abs(e2, e1 + 1.0) < 1e-5
