@@ -62,10 +62,18 @@ def main():
         raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
     import __graft_entry__
     import torch.distributed as dist
+    # EDTTS_BENCH_REHEARSAL=1: all ranks share cuda:0 and the collective runs over gloo -- exercises the multi-rank code path on
+    # a one-GPU box; the numbers it prints are NOT a scaling measurement.
+    rehearsal = os.environ.get("EDTTS_BENCH_REHEARSAL", "0") == "1"
+    if rehearsal:
+        local_rank = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     if rank == 0:
         __graft_entry__.build()  # (re)build the HIP library once; the other ranks load it after the barrier
     if world > 1:
@@ -116,7 +124,7 @@ def main():
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        tt = torch.tensor([dt], device="cpu" if rehearsal else dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     assert out.shape == (world * B, T, cfg.n_mels) and bool(torch.isfinite(out[:2]).all())
@@ -133,6 +141,8 @@ def main():
                    "parallelism": f"batch-sharded x{world}, all-gather of the final mel batch" if world > 1 else "single GPU"},
         "mels_per_s": world * B / (dt / args.steps),
     }
+    if rehearsal:
+        result["note"] = "REHEARSAL: ranks share one GPU, gloo collective -- not a scaling measurement"
 
     if world == 1 and not profile:
         result["note"] = "EDTTS_BENCH_NO_EVENTS=1: roofline leg skipped"

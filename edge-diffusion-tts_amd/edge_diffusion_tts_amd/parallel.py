@@ -34,6 +34,9 @@ def gather_batch(local: torch.Tensor, total: int, group=None) -> torch.Tensor:
     if local.shape[0] != sizes[rank]:
         raise ValueError(f"rank {rank}: local shard has {local.shape[0]} rows, expected {sizes[rank]}")
     local = local.contiguous()
+    if local.is_cuda and dist.get_backend(group) == "gloo":
+        # rehearsal only (e.g. several ranks sharing one GPU): gloo moves host memory, so stage through the CPU
+        return gather_batch(local.cpu(), total, group).to(local.device)
     if len(set(sizes)) == 1:  # the common case: one in-place collective into the output buffer
         out = torch.empty((total,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
         dist.all_gather_into_tensor(out, local, group=group)
