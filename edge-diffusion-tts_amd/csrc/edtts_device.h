@@ -617,4 +617,24 @@ EDTTS_DEV float ddpm_elem(float x, float e, float n, DdpmCoef c) {
   return mean + t3;
 }
 
+// Philox4x32-10 counter-based generator (Salmon et al., SC'11) -> four standard normals per call (Box-Muller).
+// counter = (element index lo, hi, step, 0), key = (seed lo, hi): every (seed, step, element) gets its own stream, so the
+// result does not depend on how elements are distributed over waves / GPUs.
+EDTTS_DEV f4 philox_normal4(unsigned long long seed, unsigned step, unsigned long long index) {
+  unsigned c0 = (unsigned)index, c1 = (unsigned)(index >> 32), c2 = step, c3 = 0u;
+  unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
+#pragma unroll
+  for (int i = 0; i < 10; ++i) {
+    const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
+    const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1;
+    c1 = (unsigned)p1; c3 = (unsigned)p0; c0 = n0; c2 = n2;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  const float inv = 2.3283064365386963e-10f;  // 2^-32
+  const float u0 = ((float)c0 + 1.0f) * inv, u1 = (float)c1 * inv, u2 = ((float)c2 + 1.0f) * inv, u3 = (float)c3 * inv;
+  const float r0 = sqrtf(-2.0f * __logf(u0 > 1.0f ? 1.0f : u0)), r1 = sqrtf(-2.0f * __logf(u2 > 1.0f ? 1.0f : u2));
+  const float a0 = 6.28318530717958647692f * u1, a1 = 6.28318530717958647692f * u3;
+  return f4{r0 * __cosf(a0), r0 * __sinf(a0), r1 * __cosf(a1), r1 * __sinf(a1)};
+}
+
 }  // namespace edtts

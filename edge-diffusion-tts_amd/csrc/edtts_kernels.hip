@@ -306,7 +306,11 @@ struct KArgs {
   const float* stream;
   // tail outputs
   float *eps, *x_prev, *x0;
-  float c_s1m, c_sab, c_sabp, c_dir;
+  float c_s1m, c_sab, c_sabp, c_dir;      // DDIM tail scalars
+  float p_coef1, p_coef2, p_sd;           // DDPM tail scalars (schedule.py:227-237)
+  const float* noise;                     // DDPM tail: injected noise [B,T,MEL] of this step, or null -> Philox
+  unsigned long long seed;
+  unsigned step;
 };
 
 // block -> wave tile mapping with an XCD-aware remap: the hardware deals consecutive block ids round-robin over the 8
@@ -421,7 +425,7 @@ __global__ __launch_bounds__(C::THREADS) void k_prologue(KArgs a) {
 // =========================================================================================================
 // transformer layer kernel
 // =========================================================================================================
-enum { TAIL_QKV = 0, TAIL_EPS = 1, TAIL_DDIM = 2 };
+enum { TAIL_QKV = 0, TAIL_EPS = 1, TAIL_DDIM = 2, TAIL_DDPM = 3 };
 
 struct QGlobal {  // q rows in global memory, row-major [Tp][H]
   const float* base;  // row of query frame (frame tile 0, fq)
@@ -549,6 +553,15 @@ __global__ __launch_bounds__(C::THREADS) void k_layer(KArgs a) {
         const f4 ev = e[ft] + ob;
         if (TAIL == TAIL_EPS) {
           stg4(a.eps + idx, ev);
+        } else if (TAIL == TAIL_DDPM) {
+          // ancestral DDPM update (schedule.py:222-238): mean + [t>0] * sqrt(posterior variance) * noise
+          const f4 xv = ldg4(a.x + idx);
+          const f4 nz = a.noise ? ldg4(a.noise + idx) : philox_normal4(a.seed, a.step, idx >> 2);
+          const DdpmCoef cf{a.p_coef1, a.p_coef2, a.p_sd};
+          f4 xp;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) xp[r] = ddpm_elem(xv[r], ev[r], nz[r], cf);
+          stg4(a.x_prev + idx, xp);
         } else {
           // DDIM update, same operation order as schedule.py:189-199 (no fma contraction)
           const f4 xv = ldg4(a.x + idx);
@@ -873,9 +886,14 @@ struct Launcher {
   }
 
   // one decoder forward given conditioning rows + context cache already in the workspace
+  struct DdpmStep {
+    const float* noise;
+    unsigned long long seed;
+    unsigned step;
+  };
   static int forward(const Layout& lo, const float* blob, const Workspace& ws, float* wsb, int B, int T, int S, int window,
                      const float* x, const float* cond_row, int cond_bstride, int tail, float* eps, float* x_prev, float* x0,
-                     const float* coef, hipStream_t st) {
+                     const float* coef, hipStream_t st, const DdpmStep* ddpm = nullptr) {
     KArgs a;
     base_args(lo, blob, ws, wsb, B, T, S, window, &a);
     a.x = x; a.cond = cond_row; a.cond_bstride = cond_bstride;
@@ -896,6 +914,11 @@ struct Launcher {
       } else if (tail == TAIL_EPS) {
         a.eps = eps;
         PROF_LAUNCH(st, hipLaunchKernelGGL((k_layer<C, TAIL_EPS>), dim3(g), dim3(C::THREADS), layer_lds(), st, a));
+      } else if (tail == TAIL_DDPM) {
+        a.x_prev = x_prev;
+        a.p_coef1 = coef[0]; a.p_coef2 = coef[1]; a.p_sd = coef[2];
+        a.noise = ddpm->noise; a.seed = ddpm->seed; a.step = ddpm->step;
+        PROF_LAUNCH(st, hipLaunchKernelGGL((k_layer<C, TAIL_DDPM>), dim3(g), dim3(C::THREADS), layer_lds(), st, a));
       } else {
         a.x_prev = x_prev; a.x0 = x0;
         a.c_s1m = coef[0]; a.c_sab = coef[1]; a.c_sabp = coef[2]; a.c_dir = coef[3];
@@ -914,18 +937,19 @@ struct Launcher {
     HIP_TRY(hipFuncSetAttribute((const void*)k_layer<C, TAIL_QKV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     HIP_TRY(hipFuncSetAttribute((const void*)k_layer<C, TAIL_EPS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     HIP_TRY(hipFuncSetAttribute((const void*)k_layer<C, TAIL_DDIM>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    HIP_TRY(hipFuncSetAttribute((const void*)k_layer<C, TAIL_DDPM>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     done = true;
     return EDTTS_OK;
   }
 };
 
 // compiled decoder shapes: (hidden, heads, n_mels)
-#define EDTTS_DISPATCH(lo, CALL)                                                                         \
+#define EDTTS_DISPATCH(lo, ...)                                                                          \
   do {                                                                                                   \
-    if ((lo).H == 160 && (lo).HEADS == 4 && (lo).MEL == 80) { using C = Cfg<160, 4, 80, EDTTS_NF_DEFAULT>; CALL; } \
-    else if ((lo).H == 256 && (lo).HEADS == 8 && (lo).MEL == 80) { using C = Cfg<256, 8, 80>; CALL; }     \
-    else if ((lo).H == 32 && (lo).HEADS == 2 && (lo).MEL == 80) { using C = Cfg<32, 2, 80>; CALL; }       \
-    else if ((lo).H == 64 && (lo).HEADS == 4 && (lo).MEL == 16) { using C = Cfg<64, 4, 16>; CALL; }       \
+    if ((lo).H == 160 && (lo).HEADS == 4 && (lo).MEL == 80) { using C = Cfg<160, 4, 80, EDTTS_NF_DEFAULT>; __VA_ARGS__; } \
+    else if ((lo).H == 256 && (lo).HEADS == 8 && (lo).MEL == 80) { using C = Cfg<256, 8, 80>; __VA_ARGS__; }     \
+    else if ((lo).H == 32 && (lo).HEADS == 2 && (lo).MEL == 80) { using C = Cfg<32, 2, 80>; __VA_ARGS__; }       \
+    else if ((lo).H == 64 && (lo).HEADS == 4 && (lo).MEL == 16) { using C = Cfg<64, 4, 16>; __VA_ARGS__; }       \
     else return fail(EDTTS_ERR_UNSUPPORTED, "no kernel instance for hidden=%d heads=%d n_mels=%d "        \
                      "(compiled: 160/4/80, 256/8/80, 32/2/80, 64/4/16)", (lo).H, (lo).HEADS, (lo).MEL);   \
   } while (0)
@@ -1122,6 +1146,35 @@ int edtts_generate(const EdttsDims* dims, const void* packed, void* workspace, i
       const float* xin = (i == 0) ? x_T : x_work;
       TRY(Launcher<C>::forward(lo, blob, ws, wsb, B, T, S, dims->window, xin, wsb + ws.cond + i * row, 0, TAIL_DDIM, nullptr,
                                x_work, x0_out, coef_host + 4 * i, st));
+    }
+  });
+  return EDTTS_OK;
+}
+
+int edtts_sample_ddpm(const EdttsDims* dims, const void* packed, void* workspace, int B, int S, const int64_t* sem_idx,
+                      const float* x_T, int num_steps, const int64_t* t_all, const float* coef_host, const float* noise_all,
+                      uint64_t seed, float* x_out, void* stream) {
+  Layout lo;
+  TRY(make_layout(dims, &lo));
+  if (!packed || !workspace || !sem_idx || !x_T || !t_all || !coef_host || !x_out) return fail(EDTTS_ERR_ARG, "NULL pointer argument");
+  if (num_steps < 1) return fail(EDTTS_ERR_ARG, "num_steps=%d < 1", num_steps);
+  const int T = 2 * S;
+  TRY(check_shapes(lo, B, T, S));
+  hipStream_t st = (hipStream_t)stream;
+  const float* blob = (const float*)packed;
+  float* wsb = (float*)workspace;
+  Workspace ws;
+  make_workspace(lo, B, T, S, num_steps, &ws);
+  TRY(launch_cond(lo, blob, t_all, nullptr, nullptr, num_steps, wsb + ws.cond, st));  // step_idx = None (train.py:155 usage)
+  const size_t row = (size_t)lo.L * 2 * 2 * lo.H;
+  const size_t per_step = (size_t)B * T * lo.MEL;
+  EDTTS_DISPATCH(lo, {
+    TRY(Launcher<C>::set_attrs());
+    TRY(Launcher<C>::ctx(lo, blob, ws, wsb, B, S, sem_idx, nullptr, st));
+    for (int i = 0; i < num_steps; ++i) {
+      typename Launcher<C>::DdpmStep ds{noise_all ? noise_all + (size_t)i * per_step : nullptr, (unsigned long long)seed, (unsigned)i};
+      TRY(Launcher<C>::forward(lo, blob, ws, wsb, B, T, S, dims->window, i == 0 ? x_T : x_out, wsb + ws.cond + i * row, 0, TAIL_DDPM,
+                               nullptr, x_out, nullptr, coef_host + 3 * i, st, &ds));
     }
   });
   return EDTTS_OK;

@@ -23,6 +23,7 @@ class EdgeInference:
         self.encoder = encoder
         self.decoder = decoder
         self.device = cfg.device
+        self._t_cache = {}
 
     @torch.no_grad()
     def generate_mel(self, sem_idx: torch.Tensor, num_steps: int = 4, temperature: float = 1.0, *,
@@ -54,6 +55,40 @@ class EdgeInference:
         packed = self.decoder._ensure_packed()
         ws = self.decoder.workspace(B, T_out, S, len(timesteps), dev)
         return native.generate(self.decoder.dims(), packed, ws, sem_idx.contiguous(), x_T, timesteps, coefs)
+
+    @torch.no_grad()
+    def sample_ddpm(self, sem_idx: torch.Tensor, num_steps: Optional[int] = None, temperature: float = 1.0, *,
+                    x_T: Optional[torch.Tensor] = None, noise: Optional[torch.Tensor] = None, seed: int = 0,
+                    generator: Optional[torch.Generator] = None) -> torch.Tensor:
+        """Full-schedule ancestral (DDPM) sampler: for t = T-1 ... T-num_steps: eps = decoder(x, t, sem_idx) (step_idx=None),
+        x = schedule.ddpm_step(x, t, eps).  This is the loop BASELINE config 5 names; the reference never wrote it (its
+        generate_mel cannot exceed 16 steps) but ships both pieces (train.py:155, schedule.py:204-238).
+        One C-ABI call: conditioning rows of all steps and the cross-attention cache are built once, the DDPM update is fused
+        into every step's last layer.  ``noise`` [num_steps, B, 2S, n_mels] injects the per-step draws (parity); otherwise an
+        in-kernel Philox generator keyed by (seed, step, element) supplies them.  Graph-capturable."""
+        B, S = sem_idx.shape
+        T_out = 2 * S
+        dev = sem_idx.device if sem_idx.is_cuda else torch.device(self.device)
+        sem_idx = sem_idx.to(dev).contiguous()
+        n = self.cfg.diff_steps if num_steps is None else int(num_steps)
+        if not 1 <= n <= self.cfg.diff_steps:
+            raise ValueError(f"num_steps must be in [1, {self.cfg.diff_steps}]")
+        if x_T is None:
+            x_T = torch.randn(B, T_out, self.cfg.n_mels, device=dev, generator=generator) * temperature
+        x_T = x_T.to(device=dev, dtype=torch.float32).contiguous()
+        ts = list(range(self.cfg.diff_steps - 1, self.cfg.diff_steps - 1 - n, -1))
+        key = (n, str(dev))
+        if key not in self._t_cache:  # device copy made once (an H2D copy is not allowed inside graph capture)
+            self._t_cache[key] = torch.tensor(ts, dtype=torch.int64, device=dev)
+        t_all = self._t_cache[key]
+        coefs = [self.schedule.ddpm_coefficients(t) for t in ts]
+        if noise is not None:
+            if tuple(noise.shape) != (n, B, T_out, self.cfg.n_mels):
+                raise ValueError(f"noise must be [{n}, {B}, {T_out}, {self.cfg.n_mels}]")
+            noise = noise.to(device=dev, dtype=torch.float32).contiguous()
+        packed = self.decoder._ensure_packed()
+        ws = self.decoder.workspace(B, T_out, S, n, dev)
+        return native.sample_ddpm(self.decoder.dims(), packed, ws, sem_idx, x_T, t_all, coefs, noise, seed)
 
     # alias some callers may expect from the task description; not part of the reference API (SURVEY.md F1)
     generate = generate_mel

@@ -18,7 +18,7 @@ LIB_PATH = os.environ.get("EDTTS_LIB", os.path.join(os.path.dirname(_PKG_DIR), "
 EXPORTED_SYMBOLS = (
     "edtts_version", "edtts_last_error", "edtts_num_global_slots", "edtts_num_layer_slots", "edtts_global_slot_name",
     "edtts_layer_slot_name", "edtts_packed_bytes", "edtts_pack_weights", "edtts_workspace_bytes", "edtts_decoder_forward",
-    "edtts_ddim_step", "edtts_ddpm_step", "edtts_generate", "edtts_dsconv_forward", "edtts_profile_enable",
+    "edtts_ddim_step", "edtts_ddpm_step", "edtts_generate", "edtts_sample_ddpm", "edtts_dsconv_forward", "edtts_profile_enable",
     "edtts_profile_collect",
 )
 
@@ -63,6 +63,7 @@ def lib() -> C.CDLL:
     L.edtts_ddpm_step.argtypes = [vp, vp, vp, vp, i32, vp, vp, vp, i32, sz, vp, vp, vp]
     L.edtts_generate.argtypes = [C.POINTER(EdttsDims), vp, vp, i32, i32, vp, vp, i32, C.POINTER(C.c_int64),
                                  C.POINTER(f32), vp, vp, vp]
+    L.edtts_sample_ddpm.argtypes = [C.POINTER(EdttsDims), vp, vp, i32, i32, vp, vp, i32, vp, C.POINTER(f32), vp, C.c_uint64, vp, vp]
     L.edtts_dsconv_forward.argtypes = [vp] * 6 + [i32] * 6 + [vp, vp, vp]
     L.edtts_profile_enable.argtypes = [i32]
     L.edtts_profile_collect.argtypes = [C.POINTER(C.c_double), C.POINTER(i32)]
@@ -151,6 +152,20 @@ def generate(dims: EdttsDims, packed: torch.Tensor, workspace: torch.Tensor, sem
     lib().edtts_generate(C.byref(dims), packed.data_ptr(), workspace.data_ptr(), B, S, _dev_ptr(sem_idx, torch.int64, "sem_idx"),
                          _dev_ptr(x_T, torch.float32, "x_T"), n, ts, cf, x_work.data_ptr(), x0.data_ptr(), _stream(x_T.device))
     return x0
+
+
+def sample_ddpm(dims: EdttsDims, packed: torch.Tensor, workspace: torch.Tensor, sem_idx: torch.Tensor, x_T: torch.Tensor,
+                t_all: torch.Tensor, coefs: Sequence[Tuple[float, float, float]], noise_all: Optional[torch.Tensor], seed: int) -> torch.Tensor:
+    B, S = sem_idx.shape
+    n = t_all.numel()
+    flat = [float(v) for c in coefs for v in c]
+    cf = (C.c_float * (3 * n))(*flat)
+    out = torch.empty_like(x_T)
+    lib().edtts_sample_ddpm(C.byref(dims), packed.data_ptr(), workspace.data_ptr(), B, S, _dev_ptr(sem_idx, torch.int64, "sem_idx"),
+                            _dev_ptr(x_T, torch.float32, "x_T"), n, _dev_ptr(t_all, torch.int64, "t_all"), cf,
+                            _dev_ptr(noise_all, torch.float32, "noise"), C.c_uint64(seed & 0xFFFFFFFFFFFFFFFF), out.data_ptr(),
+                            _stream(x_T.device))
+    return out
 
 
 def ddim_step(alpha_bar: torch.Tensor, x_t: torch.Tensor, t: torch.Tensor, t_prev: torch.Tensor, eps: torch.Tensor, eta: float,

@@ -46,6 +46,9 @@ class DiffusionSchedule:
         ab_prev = torch.cat([torch.ones(1, dtype=torch.float32), self.alpha_bar[:-1]])
         self.posterior_variance = self.betas * (1.0 - ab_prev) / (1.0 - self.alpha_bar)
         self.lambda_t = torch.log(self.sqrt_alpha_bar / self.sqrt_one_minus_alpha_bar)
+        # host copies for the per-step scalars of the fused samplers: no device read (and no sync) at call time, which
+        # keeps generate_mel / sample_ddpm capturable into a hipGraph
+        self._host = {n: getattr(self, n).numpy().copy() for n in ("alphas", "alpha_bar", "betas", "posterior_variance")}
         if str(device) != "cpu":
             self.to(device)
 
@@ -112,11 +115,27 @@ class DiffusionSchedule:
         def sqrt32(v):
             return f32(np.sqrt(np.float64(v)))
 
-        tab = self.alpha_bar.detach().to("cpu")
-        ab = f32(tab[t].item())
-        ab_prev = f32(tab[t_prev].item()) if t_prev >= 0 else f32(1.0)
+        tab = self._host["alpha_bar"]
+        ab = f32(tab[t])
+        ab_prev = f32(tab[t_prev]) if t_prev >= 0 else f32(1.0)
         one = f32(1.0)
         with np.errstate(divide="ignore", invalid="ignore"):
             sigma = f32(eta) * sqrt32(((one - ab_prev) / (one - ab)) * (one - ab / ab_prev))
         return (float(sqrt32(one - ab)), float(sqrt32(ab)), float(sqrt32(ab_prev)),
                 float(sqrt32((one - ab_prev) - sigma * sigma)))
+
+    def ddpm_coefficients(self, t: int) -> Tuple[float, float, float]:
+        """fp32 scalars (1/sqrt(alpha_t), beta_t/sqrt(1-alpha_bar_t), [t>0]*sqrt(posterior_variance_t)) of one ancestral
+        step (schedule.py:227-237), every operation correctly rounded to fp32 (same convention as ddim_coefficients)."""
+        import numpy as np
+        f32 = np.float32
+
+        def sqrt32(v):
+            return f32(np.sqrt(np.float64(v)))
+
+        al = f32(self._host["alphas"][t])
+        ab = f32(self._host["alpha_bar"][t])
+        be = f32(self._host["betas"][t])
+        var = f32(self._host["posterior_variance"][t])
+        one = f32(1.0)
+        return (float(one / sqrt32(al)), float(be / sqrt32(one - ab)), float((one if t > 0 else f32(0.0)) * sqrt32(var)))

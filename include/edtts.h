@@ -115,6 +115,20 @@ int edtts_generate(const EdttsDims* dims, const void* packed, void* workspace, i
                    const int64_t* sem_idx, const float* x_T, int num_steps, const int64_t* timesteps_host,
                    const float* coef_host, float* x_work, float* x0_out, void* stream);
 
+/* ---- full-schedule ancestral sampler  (BASELINE config 5; schedule.py:204-238 applied num_steps times) -----------
+ * The loop the reference implies but never wrote: for i = 0 .. num_steps-1, t = t_first - i:
+ *     eps = decoder(x, t, sem_idx, step_idx=None);   x = ddpm_step(x, t, eps)
+ * with the conditioning rows of all steps and the cross-attention K/V computed once, and the DDPM update
+ * fused into the last transformer layer of every step.  x_T [B,2S,n_mels]; t_all (device) int64[num_steps] =
+ * the timesteps in the order they are visited; coef (host) float[num_steps*3] = {1/sqrt(alpha_t),
+ * beta_t/sqrt(1-alpha_bar_t), [t>0]*sqrt(posterior_variance_t)} per step (schedule.py:227-237).
+ * Noise: noise_all [num_steps,B,2S,n_mels] if non-NULL (parity runs inject the draws the oracle used),
+ * otherwise standard normals from an in-kernel Philox4x32-10 generator keyed by (seed, step, element).
+ * The workspace must have been sized with cond_rows = num_steps.  x_out receives x after the last step. */
+int edtts_sample_ddpm(const EdttsDims* dims, const void* packed, void* workspace, int B, int S,
+                      const int64_t* sem_idx, const float* x_T, int num_steps, const int64_t* t_all,
+                      const float* coef_host, const float* noise_all, uint64_t seed, float* x_out, void* stream);
+
 /* ---- depthwise-separable Conv1d  (layers/conv.py:25-64, DepthwiseSeparableConv.forward) -----------------
  * Standalone exported layer (named by the north star; the decoder never calls it).
  * x [B,C_in,T] channel-first; dw [C_in,k] depthwise taps (stride 1, zero pad k/2, no bias); pw [C_out,C_in],

@@ -269,6 +269,20 @@ def generate_mel(sd: SD, alpha_bar: Tensor, sem_idx: Tensor, x_T: Tensor, num_st
     return x0
 
 
+def sample_ddpm(sd: SD, tabs: Dict[str, Tensor], sem_idx: Tensor, x_T: Tensor, noise_all: Tensor, num_steps: int,
+                *, heads: int = 4, window: Optional[int] = 64) -> Tensor:
+    """The full-schedule ancestral loop of BASELINE config 5: decoder with step_idx=None (as train.py:155 calls
+    it) followed by ddpm_step (schedule.py:204-238), for t = T-1 ... T-num_steps, with the per-step noise injected."""
+    T = tabs["alpha_bar"].shape[0]
+    B = sem_idx.shape[0]
+    x = x_T
+    for i in range(num_steps):
+        tt = torch.full((B,), T - 1 - i, dtype=torch.long)
+        eps = decoder_forward(sd, x, tt, sem_idx, None, heads=heads, window=window)
+        x = ddpm_step(tabs, x, tt, eps, noise_all[i])
+    return x
+
+
 # ------------------------------------------------------------------------------------------------
 # standalone exported layer named by north_star (not called by the decoder, SURVEY.md F3)
 # ------------------------------------------------------------------------------------------------

@@ -360,3 +360,79 @@ def test_weights_repacked_after_update():
         dec.out_proj.bias.add_(1.0)
     e2 = dec(cu(x), cu(t), cu(sem), cu(si)).cpu()
     assert max_abs(e2, e1 + 1.0) < 1e-5
+
+
+def _ddpm_setup(diff_steps, B, S, seed):
+    cfg = CFG(device=DEV, diff_steps=diff_steps)
+    dec = make_decoder(cfg, 0)
+    sch = DiffusionSchedule(cfg.diff_steps).to(DEV)
+    infer = EdgeInference(cfg, sch, torch.nn.Identity(), dec)
+    gen = torch.Generator().manual_seed(seed)
+    sem = torch.randint(0, 512, (B, S), generator=gen)
+    x_T = torch.randn(B, 2 * S, 80, generator=gen)
+    return cfg, infer, sem, x_T, gen
+
+
+def test_sample_ddpm_injected_noise_vs_oracle():
+    """BASELINE config 5's loop (decoder with step_idx=None + ddpm_step), short schedule, per-step noise injected so the
+    CPU oracle sees the same draws.  Early steps multiply by 1/sqrt(alpha) ~ 100, so the
+    comparison is relative to the state's magnitude."""
+    cfg, infer, sem, x_T, gen = _ddpm_setup(50, 2, 24, 3)
+    n = 6
+    noise = torch.randn(n, 2, 48, 80, generator=gen)
+    out = infer.sample_ddpm(cu(sem), n, x_T=cu(x_T), noise=cu(noise)).cpu()
+    ref = O.sample_ddpm(synth_state_dict(cfg, 0), O.schedule_tables(50), sem, x_T, noise, n)
+    scale = float(ref.abs().max())
+    assert bool(torch.isfinite(out).all()) and max_abs(out, ref) < 2e-4 * max(scale, 1.0), (max_abs(out, ref), scale)
+    # one step == public API pieces: decoder.forward + DiffusionSchedule.ddpm_step with the same noise (bitwise)
+    one = infer.sample_ddpm(cu(sem), 1, x_T=cu(x_T), noise=cu(noise[:1]))
+    tt = torch.full((2,), 49, device=DEV)
+    eps = infer.decoder(cu(x_T), tt, cu(sem), None)
+    step = infer.schedule.ddpm_step(cu(x_T), tt, eps, noise=cu(noise[0]))
+    assert torch.equal(one, step)
+
+
+def test_sample_ddpm_philox_noise():
+    """In-kernel Philox noise: deterministic per seed, different across seeds / steps, standard-normal moments, and the last
+    step (t = 0) adds no noise (schedule.py:236)."""
+    cfg, infer, sem, x_T, _ = _ddpm_setup(20, 4, 64, 5)
+    a = infer.sample_ddpm(cu(sem), 3, x_T=cu(x_T), seed=7)
+    b = infer.sample_ddpm(cu(sem), 3, x_T=cu(x_T), seed=7)
+    c = infer.sample_ddpm(cu(sem), 3, x_T=cu(x_T), seed=8)
+    assert torch.equal(a, b) and not torch.equal(a, c) and bool(torch.isfinite(a).all())
+    # recover the noise of one step: x_1step(seed) - x_1step(zero noise) = sd * n
+    z = infer.sample_ddpm(cu(sem), 1, x_T=cu(x_T), noise=torch.zeros(1, 4, 128, 80, device=DEV))
+    p = infer.sample_ddpm(cu(sem), 1, x_T=cu(x_T), seed=11)
+    sd_ = infer.schedule.ddpm_coefficients(19)[2]
+    nz = ((p - z) / sd_).flatten().double().cpu()
+    assert abs(float(nz.mean())) < 0.02 and abs(float(nz.std()) - 1.0) < 0.02
+    assert abs(float((nz ** 3).mean())) < 0.05 and abs(float((nz ** 4).mean()) - 3.0) < 0.15
+    # full schedule down to t = 0 runs and stays finite
+    full = infer.sample_ddpm(cu(sem[:1]), None, x_T=cu(x_T[:1]), seed=1)
+    assert full.shape == (1, 128, 80) and bool(torch.isfinite(full).all())
+
+
+def test_samplers_are_graph_capturable():
+    """The C ABI never allocates or synchronises and takes per-step scalars by value, so a whole generate_mel (23 launches)
+    or DDPM loop can be captured into a hipGraph and replayed on new inputs written into the static buffers."""
+    cfg, infer, sem, x_T, gen = _ddpm_setup(1000, 3, 48, 9)
+    sem_s, x_s = cu(sem).clone(), cu(x_T).clone()
+    eager = infer.generate_mel(sem_s, 4, x_T=x_s)          # warm-up: packs weights, sizes the workspace, sets attributes
+    eager_d = infer.sample_ddpm(sem_s, 8, x_T=x_s, seed=3)
+    torch.cuda.synchronize()
+    g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g1):
+        out_g = infer.generate_mel(sem_s, 4, x_T=x_s)
+    with torch.cuda.graph(g2):
+        out_d = infer.sample_ddpm(sem_s, 8, x_T=x_s, seed=3)
+    g1.replay(); g2.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out_g, eager) and torch.equal(out_d, eager_d)
+    # new inputs through the same static buffers
+    sem2 = torch.randint(0, 512, tuple(sem.shape), generator=gen)
+    x2 = torch.randn(tuple(x_T.shape), generator=gen)
+    sem_s.copy_(cu(sem2)); x_s.copy_(cu(x2))
+    g1.replay(); g2.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out_g, infer.generate_mel(cu(sem2), 4, x_T=cu(x2)))
+    assert torch.equal(out_d, infer.sample_ddpm(cu(sem2), 8, x_T=cu(x2), seed=3))
