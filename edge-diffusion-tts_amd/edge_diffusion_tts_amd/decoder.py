@@ -86,6 +86,49 @@ class EdgeDiffusionDecoder(nn.Module):
     def reset_parameters(self) -> None:
         self._fix_bias_init()
 
+    # ------------------------------------------------------------------------------------------ checkpoint interop
+    def load_state_dict(self, state_dict, strict: bool = True, **kw):
+        """Accepts the reference's decoder state-dicts as they are saved in practice: plain keys
+        (train.py:195,291-297; generate_sample.py:51) and keys prefixed with ``_orig_mod.`` when the decoder had been
+        wrapped by torch.compile before saving (train.py:84-86 + :195; only train_v2.py:339 unwraps it).  Tensors are
+        converted to fp32; positional tables shorter/longer than this module's are rejected by the normal shape check."""
+        sd = {}
+        for k, v in state_dict.items():
+            k = k[len("_orig_mod."):] if k.startswith("_orig_mod.") else k
+            if k.endswith("rope.cos_cached") or k.endswith("rope.sin_cached"):  # non-persistent in the reference, tolerated
+                continue
+            sd[k] = v.to(torch.float32) if torch.is_tensor(v) and v.is_floating_point() else v
+        return super().load_state_dict(sd, strict=strict, **kw)
+
+    @classmethod
+    def from_checkpoint(cls, checkpoint, cfg=None, device=None, **kw) -> "EdgeDiffusionDecoder":
+        """Build a decoder from a reference checkpoint dict (or a path to one): ``{"decoder": state_dict, "cfg": dict, ...}``
+        as written by train.py:291-297 / train_v2.py:335-341 and read by generate_sample.py:38-51.  ``cfg`` overrides the
+        stored config; ``codebook_size`` follows the checkpoint's token embedding (FSQ runs have 2304 codes, train_v2.py:246)."""
+        from .config import CFG
+        if isinstance(checkpoint, (str, bytes)) or hasattr(checkpoint, "__fspath__"):
+            checkpoint = torch.load(checkpoint, map_location="cpu", weights_only=False)
+        sd = checkpoint["decoder"] if "decoder" in checkpoint else checkpoint
+        if cfg is None:
+            stored = checkpoint.get("cfg") if isinstance(checkpoint, dict) else None
+            if stored is None:
+                cfg = CFG()
+            elif isinstance(stored, dict):
+                cfg = CFG.from_dict(dict(stored))
+            else:  # a pickled reference CFG object: copy the fields both classes share
+                cfg = CFG.from_dict({k: getattr(stored, k) for k in CFG.__dataclass_fields__ if hasattr(stored, k) and k != "phase"})
+        tok = next((v for k, v in sd.items() if k.endswith("token_emb.weight")), None)
+        if tok is not None and tok.shape[0] != cfg.codebook_size:
+            cfg.codebook_size = int(tok.shape[0])
+        pe = next((v for k, v in sd.items() if k.endswith("pos_emb.pe") and "context" not in k), None)
+        cpe = next((v for k, v in sd.items() if k.endswith("context_pos_emb.pe")), None)
+        dec = cls(cfg, max_len=int(pe.shape[0]) if pe is not None else 1000,
+                  max_context_len=int(cpe.shape[0]) if cpe is not None else 512, **kw)
+        dec.load_state_dict(sd)
+        if device is not None:
+            dec = dec.to(device)
+        return dec.eval()
+
     # ------------------------------------------------------------------------------------------ native state
     def dims(self) -> native.EdttsDims:
         c = self.cfg

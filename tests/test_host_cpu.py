@@ -146,3 +146,26 @@ def test_product_package_never_imports_the_oracle():
             src = open(os.path.join(pkg, f)).read()
             assert not re.search(r"^\s*(from|import)\s+\.*oracle", src, re.M), f
             assert "edtts_oracle" not in src, f
+
+
+def test_checkpoint_interop(tmp_path):
+    """Reference checkpoint layouts (train.py:291-297, train_v2.py:335-341), `_orig_mod.` prefixes left by torch.compile,
+    FSQ-sized codebooks, fp16/fp64 tensors."""
+    cfg = CFG(device="cpu")
+    sd = synth_state_dict(cfg, 4)
+    # compiled-module prefix + a non-persistent RoPE buffer that older snapshots carried
+    ck = {"decoder": {"_orig_mod." + k: v.double() for k, v in sd.items()}, "cfg": cfg.to_dict(), "encoder_proj": {}, "encoder_vq": {}}
+    ck["decoder"]["_orig_mod.layers.0.cross_attn.rope.cos_cached"] = torch.zeros(1, 1, 8, 40)
+    path = tmp_path / "edge_model_final.pt"
+    torch.save(ck, path)
+    dec = EdgeDiffusionDecoder.from_checkpoint(str(path))
+    for k, v in dec.state_dict().items():
+        assert torch.equal(v, sd[k]) and v.dtype == torch.float32, k
+    # FSQ runs: 2304 semantic codes, config still says 512 (config.py:97,100; train_v2.py:246)
+    cfg2 = CFG(device="cpu", codebook_size=2304)
+    sd2 = synth_state_dict(cfg2, 5)
+    dec2 = EdgeDiffusionDecoder.from_checkpoint({"decoder": sd2, "cfg": CFG(device="cpu").to_dict()})
+    assert dec2.cfg.codebook_size == 2304 and dec2.dims().codebook_size == 2304
+    # bare state-dict, strict mismatch still raises
+    with pytest.raises(RuntimeError):
+        EdgeDiffusionDecoder(cfg).load_state_dict({k: v for k, v in sd.items() if "ffn" not in k})
