@@ -617,6 +617,42 @@ EDTTS_DEV float ddpm_elem(float x, float e, float n, DdpmCoef c) {
   return mean + t3;
 }
 
+// Multistep x0-solver update of one element (schedule.py:339-438), same operation order, no fma contraction.
+struct LmsCoef {
+  int mode;
+  float p0, p1, c0, c1, rinv, cB, cC;
+};
+EDTTS_DEV void lms_elem(float x, float out, float h_new, float h_old, const LmsCoef& k, float& x0, float& xn) {
+#pragma clang fp contract(off)
+  float a = k.p0 * x;
+  float b = k.p1 * out;
+  float v = a + b;                        // schedule.py:125 (sqrt_ab * x_t - sqrt_1mab * v), or the model output itself
+  v = fminf(fmaxf(v, -3.0f), 3.0f);       // schedule.py:487
+  x0 = v;
+  float t0 = k.c0 * x;
+  float t1 = k.c1 * v;
+  float acc = t0 + t1;
+  if (k.mode == 2) {
+    float d = v - h_new;
+    float d1 = k.rinv * d;                // D1 = (1 / r) * (x0_pred - x0_prev)
+    float t2 = k.cB * d1;
+    t2 = t2 * 0.5f;
+    acc = acc + t2;
+  } else if (k.mode == 3) {
+    float d1 = v - h_old;                 // D1 = x0_preds[0] - x0_preds[1]
+    float two = 2.0f * h_old;
+    float d2 = v - two;
+    d2 = d2 + h_new;                      // D2 = x0_preds[0] - 2 * x0_preds[1] + x0_preds[2]
+    float t2 = k.cB * d1;
+    t2 = t2 * 0.5f;
+    float t3 = k.cC * d2;
+    t3 = t3 / 6.0f;
+    acc = acc + t2;
+    acc = acc + t3;
+  }
+  xn = acc;
+}
+
 // Philox4x32-10 counter-based generator (Salmon et al., SC'11) -> four standard normals per call (Box-Muller).
 // counter = (element index lo, hi, step, 0), key = (seed lo, hi): every (seed, step, element) gets its own stream, so the
 // result does not depend on how elements are distributed over waves / GPUs.

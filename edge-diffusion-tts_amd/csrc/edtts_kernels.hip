@@ -311,6 +311,9 @@ struct KArgs {
   const float* noise;                     // DDPM tail: injected noise [B,T,MEL] of this step, or null -> Philox
   unsigned long long seed;
   unsigned step;
+  LmsCoef lms;                            // multistep-solver tail
+  const float *h_new, *h_old;             // previous x0 predictions (may alias x0_hist: read before write, same lane)
+  float *x0_hist, *x0_all;                // where this step's x0 goes (history slot; optional intermediates)
 };
 
 // block -> wave tile mapping with an XCD-aware remap: the hardware deals consecutive block ids round-robin over the 8
@@ -425,7 +428,7 @@ __global__ __launch_bounds__(C::THREADS) void k_prologue(KArgs a) {
 // =========================================================================================================
 // transformer layer kernel
 // =========================================================================================================
-enum { TAIL_QKV = 0, TAIL_EPS = 1, TAIL_DDIM = 2, TAIL_DDPM = 3 };
+enum { TAIL_QKV = 0, TAIL_EPS = 1, TAIL_DDIM = 2, TAIL_DDPM = 3, TAIL_LMS = 4 };
 
 struct QGlobal {  // q rows in global memory, row-major [Tp][H]
   const float* base;  // row of query frame (frame tile 0, fq)
@@ -553,6 +556,22 @@ __global__ __launch_bounds__(C::THREADS) void k_layer(KArgs a) {
         const f4 ev = e[ft] + ob;
         if (TAIL == TAIL_EPS) {
           stg4(a.eps + idx, ev);
+        } else if (TAIL == TAIL_LMS) {
+          const f4 xv = ldg4(a.x + idx);
+          f4 hn = splat(0.f), ho = splat(0.f);
+          if (a.lms.mode >= 2) hn = ldg4(a.h_new + idx);
+          if (a.lms.mode >= 3) ho = ldg4(a.h_old + idx);
+          f4 x0, xn;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float v0, vn;
+            lms_elem(xv[r], ev[r], hn[r], ho[r], a.lms, v0, vn);
+            x0[r] = v0;
+            xn[r] = vn;
+          }
+          stg4(a.x0_hist + idx, x0);
+          if (a.x0_all) stg4(a.x0_all + idx, x0);
+          stg4(a.x_prev + idx, xn);
         } else if (TAIL == TAIL_DDPM) {
           // ancestral DDPM update (schedule.py:222-238): mean + [t>0] * sqrt(posterior variance) * noise
           const f4 xv = ldg4(a.x + idx);
@@ -891,9 +910,14 @@ struct Launcher {
     unsigned long long seed;
     unsigned step;
   };
+  struct LmsStep {
+    LmsCoef k;
+    const float *h_new, *h_old;
+    float *x0_hist, *x0_all;
+  };
   static int forward(const Layout& lo, const float* blob, const Workspace& ws, float* wsb, int B, int T, int S, int window,
                      const float* x, const float* cond_row, int cond_bstride, int tail, float* eps, float* x_prev, float* x0,
-                     const float* coef, hipStream_t st, const DdpmStep* ddpm = nullptr) {
+                     const float* coef, hipStream_t st, const DdpmStep* ddpm = nullptr, const LmsStep* lms = nullptr) {
     KArgs a;
     base_args(lo, blob, ws, wsb, B, T, S, window, &a);
     a.x = x; a.cond = cond_row; a.cond_bstride = cond_bstride;
@@ -914,6 +938,10 @@ struct Launcher {
       } else if (tail == TAIL_EPS) {
         a.eps = eps;
         PROF_LAUNCH(st, hipLaunchKernelGGL((k_layer<C, TAIL_EPS>), dim3(g), dim3(C::THREADS), layer_lds(), st, a));
+      } else if (tail == TAIL_LMS) {
+        a.x_prev = x_prev;
+        a.lms = lms->k; a.h_new = lms->h_new; a.h_old = lms->h_old; a.x0_hist = lms->x0_hist; a.x0_all = lms->x0_all;
+        PROF_LAUNCH(st, hipLaunchKernelGGL((k_layer<C, TAIL_LMS>), dim3(g), dim3(C::THREADS), layer_lds(), st, a));
       } else if (tail == TAIL_DDPM) {
         a.x_prev = x_prev;
         a.p_coef1 = coef[0]; a.p_coef2 = coef[1]; a.p_sd = coef[2];
@@ -938,6 +966,7 @@ struct Launcher {
     HIP_TRY(hipFuncSetAttribute((const void*)k_layer<C, TAIL_EPS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     HIP_TRY(hipFuncSetAttribute((const void*)k_layer<C, TAIL_DDIM>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     HIP_TRY(hipFuncSetAttribute((const void*)k_layer<C, TAIL_DDPM>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    HIP_TRY(hipFuncSetAttribute((const void*)k_layer<C, TAIL_LMS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     done = true;
     return EDTTS_OK;
   }
@@ -1146,6 +1175,44 @@ int edtts_generate(const EdttsDims* dims, const void* packed, void* workspace, i
       const float* xin = (i == 0) ? x_T : x_work;
       TRY(Launcher<C>::forward(lo, blob, ws, wsb, B, T, S, dims->window, xin, wsb + ws.cond + i * row, 0, TAIL_DDIM, nullptr,
                                x_work, x0_out, coef_host + 4 * i, st));
+    }
+  });
+  return EDTTS_OK;
+}
+
+int edtts_sample_multistep(const EdttsDims* dims, const void* packed, void* workspace, int B, int T, int S, const int64_t* sem_idx,
+                           const float* sem_features, const float* x_T, int num_steps, const int64_t* timesteps_host,
+                           const float* coef_host, float* hist, float* x0_all, float* x_out, void* stream) {
+  Layout lo;
+  TRY(make_layout(dims, &lo));
+  if (!sem_idx && !sem_features) return fail(EDTTS_ERR_ARG, "Either sem_idx or sem_features must be provided");
+  if (!packed || !workspace || !x_T || !timesteps_host || !coef_host || !hist || !x_out) return fail(EDTTS_ERR_ARG, "NULL pointer argument");
+  if (num_steps < 1 || num_steps > lo.NSTEP)
+    return fail(EDTTS_ERR_ARG, "num_steps=%d outside [1,%d] (step_emb rows; the reference raises IndexError)", num_steps, lo.NSTEP);
+  TRY(check_shapes(lo, B, T, S));
+  hipStream_t st = (hipStream_t)stream;
+  const float* blob = (const float*)packed;
+  float* wsb = (float*)workspace;
+  Workspace ws;
+  make_workspace(lo, B, T, S, num_steps, &ws);
+  TRY(launch_cond(lo, blob, nullptr, nullptr, timesteps_host, num_steps, wsb + ws.cond, st));
+  const size_t row = (size_t)lo.L * 2 * 2 * lo.H;
+  const size_t per = (size_t)B * T * lo.MEL;
+  EDTTS_DISPATCH(lo, {
+    TRY(Launcher<C>::set_attrs());
+    TRY(Launcher<C>::ctx(lo, blob, ws, wsb, B, S, sem_features ? nullptr : sem_idx, sem_features, st));
+    for (int i = 0; i < num_steps; ++i) {
+      const float* c = coef_host + 8 * i;
+      typename Launcher<C>::LmsStep ls;
+      ls.k.mode = (int)c[0]; ls.k.p0 = c[1]; ls.k.p1 = c[2]; ls.k.c0 = c[3]; ls.k.c1 = c[4]; ls.k.rinv = c[5]; ls.k.cB = c[6]; ls.k.cC = c[7];
+      if (ls.k.mode < 1 || ls.k.mode > 3 || ls.k.mode > i + 1) return fail(EDTTS_ERR_ARG, "step %d: bad solver mode %d", i, ls.k.mode);
+      // history ring of two slots: step i writes slot i%2; newest previous = slot (i-1)%2, the one before = slot i%2
+      ls.x0_hist = hist + (size_t)(i & 1) * per;
+      ls.h_new = hist + (size_t)((i + 1) & 1) * per;
+      ls.h_old = hist + (size_t)(i & 1) * per;
+      ls.x0_all = x0_all ? x0_all + (size_t)i * per : nullptr;
+      TRY(Launcher<C>::forward(lo, blob, ws, wsb, B, T, S, dims->window, i == 0 ? x_T : x_out, wsb + ws.cond + i * row, 0, TAIL_LMS,
+                               nullptr, x_out, nullptr, nullptr, st, nullptr, &ls));
     }
   });
   return EDTTS_OK;

@@ -8,13 +8,13 @@ C ABI of include/edtts.h); there is no CPU fallback.
 __version__ = "0.1.0"
 
 from .config import CFG, TrainPhase, get_device, set_seed
-from .schedule import DiffusionSchedule
+from .schedule import DiffusionSchedule, DPMSolverPP
 from .decoder import EdgeDiffusionDecoder
 from .inference import EdgeInference
 from .conv import DepthwiseSeparableConv
 from .synth import synth_state_dict
 
 __all__ = [
-    "CFG", "TrainPhase", "get_device", "set_seed", "DiffusionSchedule", "EdgeDiffusionDecoder", "EdgeInference",
+    "CFG", "TrainPhase", "get_device", "set_seed", "DiffusionSchedule", "DPMSolverPP", "EdgeDiffusionDecoder", "EdgeInference",
     "DepthwiseSeparableConv", "synth_state_dict",
 ]

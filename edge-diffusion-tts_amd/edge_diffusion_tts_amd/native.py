@@ -18,7 +18,7 @@ LIB_PATH = os.environ.get("EDTTS_LIB", os.path.join(os.path.dirname(_PKG_DIR), "
 EXPORTED_SYMBOLS = (
     "edtts_version", "edtts_last_error", "edtts_num_global_slots", "edtts_num_layer_slots", "edtts_global_slot_name",
     "edtts_layer_slot_name", "edtts_packed_bytes", "edtts_pack_weights", "edtts_workspace_bytes", "edtts_decoder_forward",
-    "edtts_ddim_step", "edtts_ddpm_step", "edtts_generate", "edtts_sample_ddpm", "edtts_dsconv_forward", "edtts_profile_enable",
+    "edtts_ddim_step", "edtts_ddpm_step", "edtts_generate", "edtts_sample_ddpm", "edtts_sample_multistep", "edtts_dsconv_forward", "edtts_profile_enable",
     "edtts_profile_collect",
 )
 
@@ -64,6 +64,8 @@ def lib() -> C.CDLL:
     L.edtts_generate.argtypes = [C.POINTER(EdttsDims), vp, vp, i32, i32, vp, vp, i32, C.POINTER(C.c_int64),
                                  C.POINTER(f32), vp, vp, vp]
     L.edtts_sample_ddpm.argtypes = [C.POINTER(EdttsDims), vp, vp, i32, i32, vp, vp, i32, vp, C.POINTER(f32), vp, C.c_uint64, vp, vp]
+    L.edtts_sample_multistep.argtypes = [C.POINTER(EdttsDims), vp, vp, i32, i32, i32, vp, vp, vp, i32, C.POINTER(C.c_int64),
+                                         C.POINTER(f32), vp, vp, vp, vp]
     L.edtts_dsconv_forward.argtypes = [vp] * 6 + [i32] * 6 + [vp, vp, vp]
     L.edtts_profile_enable.argtypes = [i32]
     L.edtts_profile_collect.argtypes = [C.POINTER(C.c_double), C.POINTER(i32)]
@@ -166,6 +168,22 @@ def sample_ddpm(dims: EdttsDims, packed: torch.Tensor, workspace: torch.Tensor, 
                             _dev_ptr(noise_all, torch.float32, "noise"), C.c_uint64(seed & 0xFFFFFFFFFFFFFFFF), out.data_ptr(),
                             _stream(x_T.device))
     return out
+
+
+def sample_multistep(dims: EdttsDims, packed: torch.Tensor, workspace: torch.Tensor, sem_idx: Optional[torch.Tensor],
+                     sem_features: Optional[torch.Tensor], S: int, x_T: torch.Tensor, timesteps: Sequence[int],
+                     coefs: Sequence[Sequence[float]], want_intermediates: bool):
+    B, T, M = x_T.shape
+    n = len(timesteps)
+    ts = (C.c_int64 * n)(*[int(v) for v in timesteps])
+    cf = (C.c_float * (8 * n))(*[float(v) for c in coefs for v in c])
+    hist = torch.empty((2, B, T, M), dtype=torch.float32, device=x_T.device)
+    x0_all = torch.empty((n, B, T, M), dtype=torch.float32, device=x_T.device) if want_intermediates else None
+    out = torch.empty_like(x_T)
+    lib().edtts_sample_multistep(C.byref(dims), packed.data_ptr(), workspace.data_ptr(), B, T, S, _dev_ptr(sem_idx, torch.int64, "sem_idx"),
+                                 _dev_ptr(sem_features, torch.float32, "sem_features"), _dev_ptr(x_T, torch.float32, "x_T"), n, ts, cf,
+                                 hist.data_ptr(), None if x0_all is None else x0_all.data_ptr(), out.data_ptr(), _stream(x_T.device))
+    return out, x0_all
 
 
 def ddim_step(alpha_bar: torch.Tensor, x_t: torch.Tensor, t: torch.Tensor, t_prev: torch.Tensor, eps: torch.Tensor, eta: float,

@@ -129,6 +129,23 @@ int edtts_sample_ddpm(const EdttsDims* dims, const void* packed, void* workspace
                       const int64_t* sem_idx, const float* x_T, int num_steps, const int64_t* t_all,
                       const float* coef_host, const float* noise_all, uint64_t seed, float* x_out, void* stream);
 
+/* ---- multistep x0-solver sampler  (schedule.py:440-527, DPMSolverPP.sample with the updates of :339-438) -------
+ * For step i = 0 .. num_steps-1 (t = timesteps_host[i], step_idx = i as in schedule.py:475-479):
+ *     out = decoder(x, t, sem_idx | sem_features, step_idx=i)
+ *     x0  = clamp(p0*x + p1*out, -3, 3)                       (v-prediction: p0 = sqrt(ab_t), p1 = -sqrt(1-ab_t); x0-pred: 0, 1)
+ *     mode 1:  x = c0*x + c1*x0                                                               (first_order_update)
+ *     mode 2:  x = c0*x + c1*x0 + cB*(rinv*(x0 - h_new))*0.5                                  (second_order_update)
+ *     mode 3:  x = c0*x + c1*x0 + cB*(x0 - h_old)*0.5 + cC*(x0 - 2*h_old + h_new)/6           (third_order_update)
+ * fused into the last transformer layer of each step; h_new / h_old are the previous two clamped x0 predictions.
+ * coef_host: float[num_steps*8] = {mode, p0, p1, c0, c1, rinv, cB, cC} per step, computed by the host from the schedule
+ * tables with the reference's expressions.  hist: scratch [2,B,T,n_mels]; x0_all: NULL or [num_steps,B,T,n_mels] to receive
+ * every step's x0 (return_intermediates).  Exactly one of sem_idx / sem_features is non-NULL.  Workspace sized with
+ * cond_rows = num_steps (<= n_step_emb).  x_out receives the final x. */
+int edtts_sample_multistep(const EdttsDims* dims, const void* packed, void* workspace, int B, int T, int S,
+                           const int64_t* sem_idx, const float* sem_features, const float* x_T, int num_steps,
+                           const int64_t* timesteps_host, const float* coef_host, float* hist, float* x0_all,
+                           float* x_out, void* stream);
+
 /* ---- depthwise-separable Conv1d  (layers/conv.py:25-64, DepthwiseSeparableConv.forward) -----------------
  * Standalone exported layer (named by the north star; the decoder never calls it).
  * x [B,C_in,T] channel-first; dw [C_in,k] depthwise taps (stride 1, zero pad k/2, no bias); pw [C_out,C_in],

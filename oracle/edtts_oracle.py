@@ -269,6 +269,63 @@ def generate_mel(sd: SD, alpha_bar: Tensor, sem_idx: Tensor, x_T: Tensor, num_st
     return x0
 
 
+def dpmpp_timesteps(lambda_t: Tensor, num_steps: int, max_t: Optional[int] = None) -> List[int]:
+    """schedule.py:299-324 -- num_steps points equally spaced in log-SNR between lambda[max_t] and lambda[1], each mapped
+    to the nearest table index and clamped to [1, max_t]."""
+    T = lambda_t.shape[0]
+    max_t = max_t or (T - 1)
+    lam_max, lam_min = lambda_t[1].item(), lambda_t[max_t].item()
+    lams = torch.linspace(lam_min, lam_max, num_steps + 1)
+    out = []
+    for lam in lams[:-1]:
+        t = int((lambda_t - lam).abs().argmin().item())
+        out.append(max(1, min(t, max_t)))
+    return out
+
+
+def dpmpp_sample(sd: SD, tabs: Dict[str, Tensor], x_T: Tensor, sem_features: Tensor, num_steps: int = 10, order: int = 2,
+                 predict_x0: bool = False, max_t: Optional[int] = None, *, heads: int = 4, window: Optional[int] = 64,
+                 intermediates: Optional[list] = None) -> Tensor:
+    """schedule.py:440-527 (DPMSolverPP.sample) with its update rules :339-438, restated literally -- including that the
+    history of "previous timesteps" holds each step's t_prev (so the 2nd-order ratio r is lambda-wise -1) and that the
+    3rd-order differences use [x0, older, newer] in that order."""
+    a_t, s_t, lam = tabs["sqrt_alpha_bar"], tabs["sqrt_one_minus_alpha_bar"], tabs["lambda_t"]
+    max_t = max_t or 950
+    ts = dpmpp_timesteps(lam, num_steps, max_t)
+    B = x_T.shape[0]
+    x = x_T
+    x0_hist: List[Tensor] = []
+    t_hist: List[int] = []
+    for i, t in enumerate(ts):
+        tt = torch.full((B,), t, dtype=torch.long)
+        out = decoder_forward(sd, x, tt, None, torch.full((B,), i, dtype=torch.long), sem_features, heads=heads, window=window)
+        x0 = out if predict_x0 else a_t[t] * x - s_t[t] * out          # schedule.py:109-125
+        x0 = torch.clamp(x0, -3, 3)
+        if intermediates is not None:
+            intermediates.append(x0)
+        tp = ts[i + 1] if i < len(ts) - 1 else 0
+        h = lam[tp] - lam[t]
+        if order == 1 or len(x0_hist) == 0:
+            x = (s_t[tp] / s_t[t]) * x + a_t[tp] * (1 - torch.exp(-h)) * x0
+        elif order == 2 or len(x0_hist) == 1:
+            h_prev = lam[t_hist[-1]] - lam[tp]
+            r = h_prev / h
+            d1 = (1 / r) * (x0 - x0_hist[-1])
+            x = (s_t[tp] / s_t[t]) * x + a_t[tp] * (1 - torch.exp(-h)) * x0 + a_t[tp] * ((1 - torch.exp(-h)) / h + 1) * d1 * 0.5
+        else:
+            p = [x0] + x0_hist[-2:]
+            d1 = p[0] - p[1]
+            d2 = p[0] - 2 * p[1] + p[2]
+            x = ((s_t[tp] / s_t[t]) * x + a_t[tp] * (1 - torch.exp(-h)) * p[0] + a_t[tp] * ((1 - torch.exp(-h)) / h + 1) * d1 * 0.5
+                 + a_t[tp] * ((1 - torch.exp(-h)) / (h ** 2) + 0.5 / h + 0.5) * d2 / 6)
+        x0_hist.append(x0)
+        t_hist.append(tp)
+        if len(x0_hist) > 2:
+            x0_hist.pop(0)
+            t_hist.pop(0)
+    return x
+
+
 def sample_ddpm(sd: SD, tabs: Dict[str, Tensor], sem_idx: Tensor, x_T: Tensor, noise_all: Tensor, num_steps: int,
                 *, heads: int = 4, window: Optional[int] = 64) -> Tensor:
     """The full-schedule ancestral loop of BASELINE config 5: decoder with step_idx=None (as train.py:155 calls

@@ -213,6 +213,24 @@ def main():
     np.savez_compressed(os.path.join(OUT, "forward_cfg3.npz"), x_t=npf(x3), sem_idx=npf(sem3), t=np.array([600]), step_idx=np.array([1]),
                         eps=npf(e3))
 
+    # ---- 8. DPM-Solver++ sampler (schedule.py:269-534), the sampler train_v2.validate uses ----
+    from edge_diffusion_tts.schedule import DPMSolverPP as RefDPM
+    d = {}
+    featd = rnd((2, 24, cfg.semantic_dim), 51, 0)
+    xTd = rnd((2, 48, 80), 51, 1, 1.2)
+    d.update(sem_features=npf(featd), x_T=npf(xTd))
+    for order in (1, 2, 3):
+        for n in (4, 7):
+            solver = RefDPM(sch, order=order)
+            d[f"ts_o{order}_n{n}"] = npf(solver.get_time_steps(n, 950))
+            xo, inter = solver.sample(dec, xTd, featd, num_steps=n, return_intermediates=True)
+            d[f"out_o{order}_n{n}"] = npf(xo)
+            d[f"x0s_o{order}_n{n}"] = npf(torch.stack(inter))
+    solver = RefDPM(sch, order=2, predict_x0=True)
+    d["out_px0_o2_n5"] = npf(solver.sample(dec, xTd, featd, num_steps=5))
+    d["ts_default_n10"] = npf(RefDPM(sch).get_time_steps(10))
+    np.savez_compressed(os.path.join(OUT, "dpmpp.npz"), **d)
+
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f"{f}: {os.path.getsize(os.path.join(OUT, f)) / 1024:.0f} KiB")

@@ -436,3 +436,40 @@ def test_samplers_are_graph_capturable():
     torch.cuda.synchronize()
     assert torch.equal(out_g, infer.generate_mel(cu(sem2), 4, x_T=cu(x2)))
     assert torch.equal(out_d, infer.sample_ddpm(cu(sem2), 8, x_T=cu(x2), seed=3))
+
+
+def test_dpm_solver_pp(golden):
+    """DPM-Solver++ sampler through edtts_sample_multistep, against the reference's CPU run:
+    orders 1-3, 4 and 7 steps, final sample and every intermediate clamped x0; x0-prediction mode; token conditioning."""
+    from edge_diffusion_tts_amd import DPMSolverPP
+    g = golden("dpmpp")
+    cfg = CFG(device=DEV)
+    dec = make_decoder(cfg, 0)
+    sch = DiffusionSchedule(cfg.diff_steps).to(DEV)
+    for order in (1, 2, 3):
+        solver = DPMSolverPP(sch, order=order)
+        for n in (4, 7):
+            assert solver.get_time_steps(n, 950).tolist() == g[f"ts_o{order}_n{n}"].tolist()
+            out, inter = solver.sample(dec, cu(g["x_T"]), cu(g["sem_features"]), num_steps=n, return_intermediates=True)
+            assert max_abs(out.cpu(), g[f"out_o{order}_n{n}"]) < FWD_TOL, (order, n)
+            assert max_abs(torch.stack(inter).cpu(), g[f"x0s_o{order}_n{n}"]) < FWD_TOL, (order, n)
+    out = DPMSolverPP(sch, order=2, predict_x0=True).sample(dec, cu(g["x_T"]), cu(g["sem_features"]), num_steps=5)
+    assert max_abs(out.cpu(), g["out_px0_o2_n5"]) < FWD_TOL
+    assert DPMSolverPP(sch).get_time_steps(10).tolist() == g["ts_default_n10"].tolist()
+    # fused call == the public step-by-step pieces (decoder.forward + the update methods), to rounding
+    solver = DPMSolverPP(sch, order=2)
+    ts = solver.get_time_steps(4, 950)
+    x = cu(g["x_T"])
+    B = x.shape[0]
+    hist, th = [], []
+    for i, t in enumerate(ts.tolist()):
+        tt = torch.full((B,), t, device=DEV)
+        v = dec(x, tt, None, torch.full((B,), i, device=DEV), cu(g["sem_features"]))
+        x0 = solver.model_to_x0(v, x, tt).clamp(-3, 3)
+        tp = torch.full((B,), ts[i + 1].item() if i < 3 else 0, device=DEV)
+        x = solver.first_order_update(x, x0, tt, tp) if not hist else solver.second_order_update(x, x0, hist[-1], tt, tp, th[-1])
+        hist.append(x0); th.append(tp)
+    fused = solver.sample(dec, cu(g["x_T"]), cu(g["sem_features"]), num_steps=4)
+    assert max_abs(fused, x) < 2e-5
+    with pytest.raises((IndexError, RuntimeError)):
+        solver.sample(dec, cu(g["x_T"]), cu(g["sem_features"]), num_steps=17)
