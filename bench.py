@@ -107,7 +107,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    n_layer_launches = args.steps * 4 * cfg.layers
+    n_layer_launches = args.steps * 4 * cfg.layers * 2  # a layer is one or two launches
     profile = world == 1 and os.environ.get("EDTTS_BENCH_NO_EVENTS", "0") != "1"
     if profile:
         native.profile_enable(n_layer_launches)
@@ -147,15 +147,15 @@ def main():
     if world == 1 and not profile:
         result["note"] = "EDTTS_BENCH_NO_EVENTS=1: roofline leg skipped"
     if profile:
-        layer_ms, n = native.profile_collect()
+        (ms0, n0), (ms1, n1) = native.profile_collect()
         native.profile_enable(0)
         frames = B * T
-        flops = 0.0
-        for l in range(cfg.layers):
-            flops += frames * layer_flops_per_frame(cfg.hidden, cfg.n_mels, S, T, cfg.attn_window_size, l == cfg.layers - 1)
-        flops_per_launch = flops / cfg.layers  # average over the L launches of one decoder forward
-        avg_ms = layer_ms / max(n, 1)
-        achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
+        H, M, W = cfg.hidden, cfg.n_mels, cfg.attn_window_size
+        nbar = sum(min(i + W, T - 1) - max(i - W, 0) + 1 for i in range(T)) / T
+        attn_flops = frames * (2 * H * H * 3 + 4 * nbar * H + 4 * S * H)              # proj, q_proj, out_proj + both attentions
+        ffn_flops = [frames * (2 * H * 4 * H + 2 * 2 * H * H + (2 * M * H if l == cfg.layers - 1 else 6 * H * H)) for l in range(cfg.layers)]
+        flops = cfg.layers * attn_flops + sum(ffn_flops)                               # one decoder forward, all layer kernels
+        layer_ms = ms0 + ms1
         traffic = None
         pmc = os.path.join(REPO, "profiles", "r01_pmc_k_layer.json")
         if os.path.exists(pmc):
@@ -163,11 +163,26 @@ def main():
                 traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        result["roofline"] = {"bound": "mfma", "kernel": "k_layer (fused transformer layer)", "achieved": achieved,
-                              "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS,
-                              "traffic": traffic, "avg_launch_ms": avg_ms, "launches_timed": n,
-                              "algorithmic_gflop_per_launch": flops_per_launch / 1e9,
-                              "layer_kernels_share_of_step": layer_ms / args.steps / ms_per_step}
+
+        def roof(name, fl_per_launch, ms, n):
+            avg = ms / max(n, 1)
+            ach = fl_per_launch / (avg * 1e-3) / 1e12
+            return {"bound": "mfma", "kernel": name, "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": ach / PEAK_F32_MFMA_TFLOPS, "avg_launch_ms": avg, "launches_timed": n,
+                    "algorithmic_gflop_per_launch": fl_per_launch / 1e9}
+        if n1 == 0:   # fused layer kernel
+            result["roofline"] = roof("k_layer (fused transformer layer)", flops / cfg.layers, ms0, n0)
+        else:         # layer = attention half + FFN/tail half; the dominant one (by time) is the roofline kernel
+            r_attn = roof("k_layer<PART_ATTN> (self + cross attention, projections)", attn_flops, ms0, n0)
+            r_ffn = roof("k_layer<PART_FFN> (SwiGLU FFN + QKV / output tail)", sum(ffn_flops) / cfg.layers, ms1, n1)
+            dom, oth = (r_attn, r_ffn) if ms0 >= ms1 else (r_ffn, r_attn)
+            result["roofline"] = dom
+            result["roofline_other_kernel"] = oth
+            result["roofline_layer_pair"] = {"achieved": flops / cfg.layers / ((ms0 + ms1) / max(n0, 1) * 1e-3) / 1e12,
+                                             "frac": flops / cfg.layers / ((ms0 + ms1) / max(n0, 1) * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                                             "ms_per_layer": (ms0 + ms1) / max(n0, 1), "unit": "TFLOP/s"}
+        result["roofline"]["traffic"] = traffic
+        result["roofline"]["layer_kernels_share_of_step"] = layer_ms / args.steps / ms_per_step
         total_flops = 4 * flops + 4 * frames * 2 * cfg.n_mels * cfg.hidden + 4 * frames * 6 * cfg.hidden ** 2 \
             + cfg.layers * B * S * 3 * cfg.hidden ** 2
         result["whole_call"] = {"algorithmic_tflop": total_flops / 1e12, "tflops": total_flops / (dt / args.steps) / 1e12,

@@ -54,7 +54,8 @@ static int fail(int code, const char* fmt, ...) {
 #include <vector>
 struct Profiler {
   std::vector<hipEvent_t> start, stop;
-  int used = 0;
+  std::vector<int> kinds;  // 0 = fused layer kernel or attention half, 1 = FFN + tail half
+  int used = 0, kind = 0;
   bool on() const { return !start.empty(); }
 };
 static Profiler g_prof;
@@ -63,7 +64,7 @@ static Profiler g_prof;
     const bool rec_ = g_prof.on() && g_prof.used < (int)g_prof.start.size();    \
     if (rec_) (void)hipEventRecord(g_prof.start[g_prof.used], (stream));         \
     launch_stmt;                                                                \
-    if (rec_) (void)hipEventRecord(g_prof.stop[g_prof.used++], (stream));        \
+    if (rec_) { g_prof.kinds[g_prof.used] = g_prof.kind; (void)hipEventRecord(g_prof.stop[g_prof.used++], (stream)); } \
   } while (0)
 
 // =========================================================================================================
@@ -96,6 +97,7 @@ struct LayerLayout {
   size_t n1w, ada1T, ada1b, proj_b, n2w, n3w, ada3T, ada3b, up_b, down_b, kvd, kvn, kvu;
   size_t s_qkv;   // stream: QKV of this layer            [3HT n-tiles][HT]
   size_t s_body;  // stream: proj | q_proj | out_proj | ffn   (followed in memory by s_qkv of layer+1 / s_outp)
+  size_t s_ffn;   // where the ffn part of s_body starts (entry point of the split FFN kernel)
 };
 struct Layout {
   int H, HEADS, MEL, L, DH, DHP, HT, MT, R, RT, SD, NTOK, MAXPOS, MAXCPOS, NSTEP;
@@ -141,7 +143,9 @@ static int make_layout(const EdttsDims* d, Layout* lo) {
   for (int l = 0; l < lo->L; ++l) {
     LayerLayout& y = lo->layer[l];
     y.s_qkv = o; o += 3 * HT * HT * kFrag;
-    y.s_body = o; o += (KPT * HT /*proj*/ + HT * HT /*q_proj*/ + KPT * HT /*out_proj*/ + 2 * HT * 3 * HT /*ffn*/) * kFrag;
+    y.s_body = o;
+    y.s_ffn = o + (KPT * HT /*proj*/ + HT * HT /*q_proj*/ + KPT * HT /*out_proj*/) * kFrag;
+    o = y.s_ffn + (2 * HT * 3 * HT /*ffn*/) * kFrag;
   }
   lo->s_outp = o; o += MT * HT * kFrag;
   o += 4 * HT * kFrag;  // the stream stages two phases (+ slot padding) past the last consumed fragment
@@ -443,7 +447,12 @@ struct QLds {  // q tile in this wave's LDS region, [32][QLD]
   EDTTS_DEV f2 q2(int ft, int col) const { return *reinterpret_cast<const f2*>(base + ft * 16 * ld + col); }
 };
 
-template <class C, int TAIL>
+// PART 0: the whole block in one launch.  PART 1: attention half (self + cross attention, h written back).  PART 2: FFN + tail
+// half, run with a different frames-per-wave instance (see EDTTS_NF_FFN below): the residual tile crosses HBM once more per
+// layer, which buys the FFN / QKV weight stream twice the MFMAs per fragment without inflating the attention's registers.
+enum { PART_ALL = 0, PART_ATTN = 1, PART_FFN = 2 };
+
+template <class C, int TAIL, int PART>
 __global__ __launch_bounds__(C::THREADS) void k_layer(KArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int NF = C::NF;
@@ -463,7 +472,8 @@ __global__ __launch_bounds__(C::THREADS) void k_layer(KArgs a) {
     const float* hp = a.h + rowbase * C::H + 4 * g;
 #pragma unroll
     for (int nt = 0; nt < C::HT; ++nt) {
-      const f4 pb = ldg4(a.proj_b + 16 * nt + 4 * g);
+      f4 pb = splat(0.f);
+      if (PART != PART_FFN) pb = ldg4(a.proj_b + 16 * nt + 4 * g);
 #pragma unroll
       for (int ft = 0; ft < NF; ++ft) h[nt][ft] = ldg4(hp + 16 * nt + (size_t)ft * 16 * C::H) + pb;
     }
@@ -474,13 +484,13 @@ __global__ __launch_bounds__(C::THREADS) void k_layer(KArgs a) {
 #define DIAG_ON(bit) true
 #endif
   // ---- x = x + attn(norm1(x, cond))   (transformer.py:142-146; q/k/v were produced by the previous kernel) ----
-  if (DIAG_ON(1)) {
+  if (PART != PART_FFN && DIAG_ON(1)) {
     QGlobal ql{a.q + rowbase * C::H, C::H};
     attention_fused<C, true>(ql, a.k + (size_t)b * a.Tp * C::H, a.vT + (size_t)b * C::VR * a.Tp, a.Tp, a.T, a.window, m0,
                              lane, ring, h);
   }
   // ---- x = x + cross_attn(norm2(x), context)   (transformer.py:151, mla.py:118-194) --------------------------
-  if (DIAG_ON(2)) {
+  if (PART != PART_FFN && DIAG_ON(2)) {
     f4 hn[C::HT][NF];
     rms_norm_tile<C::HT, NF>(h, a.n2w, nullptr, g, hn);
     for (int nt = 0; nt < C::HT; ++nt) {
@@ -492,10 +502,20 @@ __global__ __launch_bounds__(C::THREADS) void k_layer(KArgs a) {
       for (int ft = 0; ft < NF; ++ft) stg4(qtile + (16 * ft + fq) * C::QLD + 16 * nt + 4 * g, acc[ft]);
     }
   }
-  if (DIAG_ON(2)) {
+  if (PART != PART_FFN && DIAG_ON(2)) {
     QLds ql{qtile + fq * C::QLD, C::QLD};
     attention_fused<C, false>(ql, a.kc + (size_t)b * a.Sp * C::H, a.vcT + (size_t)b * C::VR * a.Sp, a.Sp, a.S, -1, m0, lane,
                               ring, h);
+  }
+  if (PART == PART_ATTN) {  // hand the residual tile to the FFN half
+    if (tl.valid) {
+      float* hp = a.h + rowbase * C::H + 4 * g;
+#pragma unroll
+      for (int nt = 0; nt < C::HT; ++nt)
+#pragma unroll
+        for (int ft = 0; ft < NF; ++ft) stg4(hp + 16 * nt + (size_t)ft * 16 * C::H, h[nt][ft]);
+    }
+    return;
   }
   // ---- x = x + ffn(norm3(x, cond))   (transformer.py:154-158, :13-49) ----------------------------------------
   if (DIAG_ON(4)) {
@@ -534,10 +554,10 @@ __global__ __launch_bounds__(C::THREADS) void k_layer(KArgs a) {
 #pragma unroll
         for (int ft = 0; ft < NF; ++ft) stg4(hp + 16 * nt + (size_t)ft * 16 * C::H, h[nt][ft]);
     }
-    f4 hn[C::HT][NF];
+    // h has been stored: normalise in place (the function is alias-safe) instead of keeping a second 16*NF*HT-register tile
     const float* mod = a.cond + (size_t)b * a.cond_bstride + ((size_t)(a.layer + 1) * 2) * 2 * C::H;
-    rms_norm_tile<C::HT, NF>(h, a.n1w, mod, g, hn);
-    qkv_tail<C>(ring, hn, a, b, m0, lane, tl.valid);
+    rms_norm_tile<C::HT, NF>(h, a.n1w, mod, g, h);
+    qkv_tail<C>(ring, h, a, b, m0, lane, tl.valid);
   } else {
     f4 hn[C::HT][NF];
     layer_norm_tile<C::HT, NF>(h, a.fnw, a.fnb, g, hn);
@@ -845,8 +865,19 @@ struct Workspace {
 #ifndef EDTTS_NF_DEFAULT
 #define EDTTS_NF_DEFAULT 2
 #endif
-// frames per wave of the kernel instance that serves these dims (must mirror EDTTS_DISPATCH)
-static int wave_frames(const Layout& lo) { return (lo.H == 160 && lo.HEADS == 4 && lo.MEL == 80) ? 16 * EDTTS_NF_DEFAULT : 32; }
+// Frame tiles per wave of the FFN + tail half when the layer is split into two launches (0 = do not split, the default).
+// Measured at B=256, T=512 with -DEDTTS_NF_FFN=4: the 64-frame FFN half alone reaches 121.6 TFLOP/s (77 % of peak) against
+// ~80 % MFMA-busy inside the fused kernel, but attention half 0.613 ms + FFN half 0.462 ms = 1.075 ms per layer loses to the
+// fused 1.046 ms: the second kernel's start-up (exposed loads of 4096 waves at once) and drain cost more than the stream gains.
+#ifndef EDTTS_NF_FFN
+#define EDTTS_NF_FFN 0
+#endif
+// largest frames-per-wave of any kernel instance that serves these dims: the padded length Tp is a multiple of it
+static int wave_frames(const Layout& lo) {
+  int nf = (lo.H == 160 && lo.HEADS == 4 && lo.MEL == 80) ? EDTTS_NF_DEFAULT : 2;
+  if (EDTTS_NF_FFN > nf && lo.H <= 192) nf = EDTTS_NF_FFN;
+  return 16 * nf;
+}
 
 static void make_workspace(const Layout& lo, int B, int T, int S, int cond_rows, Workspace* w) {
   const size_t H = lo.H;
@@ -870,6 +901,10 @@ template <class C>
 struct Launcher {
   static size_t ring_lds() { return 0; }
   static size_t layer_lds() { return ring_lds() + (size_t)C::WAVES * C::WF * C::QLD * sizeof(float); }
+  // split layer: attention half with this instance (C), FFN + tail half with CF (more frames per wave)
+  static constexpr bool SPLIT = (EDTTS_NF_FFN > C::NF) && C::H <= 192;
+  using CF = Cfg<C::H, C::HEADS, C::MEL, (SPLIT ? EDTTS_NF_FFN : C::NF)>;
+  static int grid_f(int B, int Tp) { return (B * (Tp / CF::WF) + CF::WAVES - 1) / CF::WAVES; }
   static int grid(int B, int Tp) { return (B * (Tp / C::WF) + C::WAVES - 1) / C::WAVES; }
   static int ctx_grid(int B, int Sp) { return (B * (Sp / 32) + kCtxWaves - 1) / kCtxWaves; }
   using C2 = Cfg<C::H, C::HEADS, C::MEL, 2>;  // geometry of the context kernel
@@ -932,25 +967,50 @@ struct Launcher {
       a.down_b = blob + y.down_b; a.stream = blob + y.s_body;
       a.kc = wsb + ws.kc + (size_t)l * B * ws.Sp * lo.H;
       a.vcT = wsb + ws.vcT + (size_t)l * B * ws.VR * ws.Sp;
+      int t_eff = tail;
       if (l + 1 < lo.L) {
         a.n1w = blob + lo.layer[l + 1].n1w;
-        PROF_LAUNCH(st, hipLaunchKernelGGL((k_layer<C, TAIL_QKV>), dim3(g), dim3(C::THREADS), layer_lds(), st, a));
+        t_eff = TAIL_QKV;
       } else if (tail == TAIL_EPS) {
         a.eps = eps;
-        PROF_LAUNCH(st, hipLaunchKernelGGL((k_layer<C, TAIL_EPS>), dim3(g), dim3(C::THREADS), layer_lds(), st, a));
       } else if (tail == TAIL_LMS) {
         a.x_prev = x_prev;
         a.lms = lms->k; a.h_new = lms->h_new; a.h_old = lms->h_old; a.x0_hist = lms->x0_hist; a.x0_all = lms->x0_all;
-        PROF_LAUNCH(st, hipLaunchKernelGGL((k_layer<C, TAIL_LMS>), dim3(g), dim3(C::THREADS), layer_lds(), st, a));
       } else if (tail == TAIL_DDPM) {
         a.x_prev = x_prev;
         a.p_coef1 = coef[0]; a.p_coef2 = coef[1]; a.p_sd = coef[2];
         a.noise = ddpm->noise; a.seed = ddpm->seed; a.step = ddpm->step;
-        PROF_LAUNCH(st, hipLaunchKernelGGL((k_layer<C, TAIL_DDPM>), dim3(g), dim3(C::THREADS), layer_lds(), st, a));
       } else {
         a.x_prev = x_prev; a.x0 = x0;
         a.c_s1m = coef[0]; a.c_sab = coef[1]; a.c_sabp = coef[2]; a.c_dir = coef[3];
-        PROF_LAUNCH(st, hipLaunchKernelGGL((k_layer<C, TAIL_DDIM>), dim3(g), dim3(C::THREADS), layer_lds(), st, a));
+      }
+      if (SPLIT) {
+        g_prof.kind = 0;
+        PROF_LAUNCH(st, hipLaunchKernelGGL((k_layer<C, TAIL_QKV, PART_ATTN>), dim3(g), dim3(C::THREADS), layer_lds(), st, a));
+        LAUNCH_CHECK("k_layer<attn>");
+        a.stream = blob + y.s_ffn;
+        g_prof.kind = 1;
+        const int gf = grid_f(B, ws.Tp);
+#define EDTTS_LAUNCH_FFN(TL) PROF_LAUNCH(st, hipLaunchKernelGGL((k_layer<CF, TL, PART_FFN>), dim3(gf), dim3(CF::THREADS), 0, st, a))
+        switch (t_eff) {
+          case TAIL_QKV: EDTTS_LAUNCH_FFN(TAIL_QKV); break;
+          case TAIL_EPS: EDTTS_LAUNCH_FFN(TAIL_EPS); break;
+          case TAIL_LMS: EDTTS_LAUNCH_FFN(TAIL_LMS); break;
+          case TAIL_DDPM: EDTTS_LAUNCH_FFN(TAIL_DDPM); break;
+          default: EDTTS_LAUNCH_FFN(TAIL_DDIM); break;
+        }
+#undef EDTTS_LAUNCH_FFN
+        g_prof.kind = 0;
+      } else {
+#define EDTTS_LAUNCH_ALL(TL) PROF_LAUNCH(st, hipLaunchKernelGGL((k_layer<C, TL, PART_ALL>), dim3(g), dim3(C::THREADS), layer_lds(), st, a))
+        switch (t_eff) {
+          case TAIL_QKV: EDTTS_LAUNCH_ALL(TAIL_QKV); break;
+          case TAIL_EPS: EDTTS_LAUNCH_ALL(TAIL_EPS); break;
+          case TAIL_LMS: EDTTS_LAUNCH_ALL(TAIL_LMS); break;
+          case TAIL_DDPM: EDTTS_LAUNCH_ALL(TAIL_DDPM); break;
+          default: EDTTS_LAUNCH_ALL(TAIL_DDIM); break;
+        }
+#undef EDTTS_LAUNCH_ALL
       }
       LAUNCH_CHECK("k_layer");
     }
@@ -962,11 +1022,15 @@ struct Launcher {
     static bool done = false;
     if (done) return EDTTS_OK;
     const int lds = (int)layer_lds();
-    HIP_TRY(hipFuncSetAttribute((const void*)k_layer<C, TAIL_QKV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    HIP_TRY(hipFuncSetAttribute((const void*)k_layer<C, TAIL_EPS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    HIP_TRY(hipFuncSetAttribute((const void*)k_layer<C, TAIL_DDIM>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    HIP_TRY(hipFuncSetAttribute((const void*)k_layer<C, TAIL_DDPM>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    HIP_TRY(hipFuncSetAttribute((const void*)k_layer<C, TAIL_LMS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    if (SPLIT) {
+      HIP_TRY(hipFuncSetAttribute((const void*)k_layer<C, TAIL_QKV, PART_ATTN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    } else {
+      HIP_TRY(hipFuncSetAttribute((const void*)k_layer<C, TAIL_QKV, PART_ALL>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+      HIP_TRY(hipFuncSetAttribute((const void*)k_layer<C, TAIL_EPS, PART_ALL>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+      HIP_TRY(hipFuncSetAttribute((const void*)k_layer<C, TAIL_DDIM, PART_ALL>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+      HIP_TRY(hipFuncSetAttribute((const void*)k_layer<C, TAIL_DDPM, PART_ALL>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+      HIP_TRY(hipFuncSetAttribute((const void*)k_layer<C, TAIL_LMS, PART_ALL>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    }
     done = true;
     return EDTTS_OK;
   }
@@ -1312,20 +1376,21 @@ int edtts_profile_enable(int max_records) {
     HIP_TRY(hipEventCreate(&b));
     g_prof.start.push_back(a); g_prof.stop.push_back(b);
   }
+  g_prof.kinds.assign(max_records, 0);
   return EDTTS_OK;
 }
 
-int edtts_profile_collect(double* layer_ms_total, int* layer_launches) {
-  if (!layer_ms_total || !layer_launches) return fail(EDTTS_ERR_ARG, "NULL pointer argument");
-  double tot = 0.0;
+int edtts_profile_collect(double* ms_by_kind, int* launches_by_kind) {
+  if (!ms_by_kind || !launches_by_kind) return fail(EDTTS_ERR_ARG, "NULL pointer argument");
+  ms_by_kind[0] = ms_by_kind[1] = 0.0;
+  launches_by_kind[0] = launches_by_kind[1] = 0;
   for (int i = 0; i < g_prof.used; ++i) {
     HIP_TRY(hipEventSynchronize(g_prof.stop[i]));
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, g_prof.start[i], g_prof.stop[i]));
-    tot += ms;
+    ms_by_kind[g_prof.kinds[i] & 1] += ms;
+    launches_by_kind[g_prof.kinds[i] & 1] += 1;
   }
-  *layer_ms_total = tot;
-  *layer_launches = g_prof.used;
   g_prof.used = 0;
   return EDTTS_OK;
 }

@@ -68,7 +68,7 @@ def lib() -> C.CDLL:
                                          C.POINTER(f32), vp, vp, vp, vp]
     L.edtts_dsconv_forward.argtypes = [vp] * 6 + [i32] * 6 + [vp, vp, vp]
     L.edtts_profile_enable.argtypes = [i32]
-    L.edtts_profile_collect.argtypes = [C.POINTER(C.c_double), C.POINTER(i32)]
+    L.edtts_profile_collect.argtypes = [C.POINTER(C.c_double), C.POINTER(i32)]  # arrays of 2
     for name in EXPORTED_SYMBOLS:
         fn = getattr(L, name)
         if fn.restype is C.c_int and name not in ("edtts_version", "edtts_num_global_slots", "edtts_num_layer_slots"):
@@ -226,8 +226,9 @@ def profile_enable(max_records: int) -> None:
     lib().edtts_profile_enable(int(max_records))
 
 
-def profile_collect() -> Tuple[float, int]:
-    """(summed device ms of the transformer-layer kernel launches recorded since the last call, launch count)."""
-    ms, n = C.c_double(0.0), C.c_int(0)
-    lib().edtts_profile_collect(C.byref(ms), C.byref(n))
-    return ms.value, n.value
+def profile_collect():
+    """((ms, launches) of the fused-layer / attention-half kernels, (ms, launches) of the FFN + tail half kernels) recorded
+    since the last call."""
+    ms, n = (C.c_double * 2)(), (C.c_int * 2)()
+    lib().edtts_profile_collect(ms, n)
+    return (ms[0], n[0]), (ms[1], n[1])

@@ -156,12 +156,13 @@ int edtts_dsconv_forward(const float* x, const float* dw, const float* pw, const
                          float* scratch, float* y, void* stream);
 
 /* ---- measurement hook (bench.py roofline leg) -----------------------------------------------------------
- * edtts_profile_enable(n > 0): from now on every transformer-layer kernel launch (k_layer, the dominant kernel)
- * is bracketed by a pair of hipEvents recorded on the stream it is launched on, up to n launches; n = 0
- * disables and releases the events.  edtts_profile_collect synchronises on the recorded events, returns the
- * summed device time (ms) and the number of launches, and resets the counter.  Not graph-capturable while on. */
+ * edtts_profile_enable(n > 0): from now on every transformer-layer kernel launch is bracketed by a pair of
+ * hipEvents recorded on the stream it is launched on, up to n launches; n = 0 disables and releases the events.
+ * A decoder layer is either one fused launch (kind 0) or two: the attention half (kind 0) and the FFN + tail half
+ * (kind 1).  edtts_profile_collect synchronises on the recorded events, returns the summed device time (ms) and
+ * the launch count per kind (arrays of 2), and resets the counter.  Not graph-capturable while on. */
 int edtts_profile_enable(int max_records);
-int edtts_profile_collect(double* layer_ms_total, int* layer_launches);
+int edtts_profile_collect(double* ms_by_kind, int* launches_by_kind);
 
 #ifdef __cplusplus
 }
