@@ -296,7 +296,12 @@ struct KArgs {
   int B, T, Tp, S, Sp, window, max_pos, max_cpos, n_tok, SD, L;
   // inputs / outputs
   const float* x;  // [B][T][MEL]
-  float *h, *q, *k, *vT;
+  float* h;
+  // q / k / v^T ping-pong between layers: a launch reads the set its predecessor wrote (q, k, vT) and writes the OTHER set
+  // (q_out, k_out, vT_out) -- blocks of one launch run at different times, and a block's QKV tail must not overwrite K/V halo
+  // rows that a neighbouring block of the same launch has yet to read for its self-attention.
+  const float *q, *k, *vT;
+  float *q_out, *k_out, *vT_out;
   float *kc, *vcT;  // cross K / V^T cache: kernel-specific base (k_ctx: whole cache; k_layer: this layer's slice)
   const int64_t* sem_idx;
   const float* sem_feat;
@@ -363,11 +368,11 @@ EDTTS_DEV void qkv_tail(WStream<C>& ring, const f4 (&hn)[C::HT][C::NF], const KA
       gemm_phase<C::HT>(ring, hn, acc);
       if (!valid) continue;
       if (which < 2) {
-        float* dst = (which == 0 ? a.q : a.k) + rowbase * C::H + 16 * nt + 4 * g;
+        float* dst = (which == 0 ? a.q_out : a.k_out) + rowbase * C::H + 16 * nt + 4 * g;
 #pragma unroll
         for (int ft = 0; ft < NF; ++ft) stg4(dst + (size_t)ft * 16 * C::H, acc[ft]);
       } else {
-        float* dst = a.vT + ((size_t)b * C::VR + 16 * nt + 4 * g) * a.Tp + m0 + fq;
+        float* dst = a.vT_out + ((size_t)b * C::VR + 16 * nt + 4 * g) * a.Tp + m0 + fq;
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -888,9 +893,9 @@ static void make_workspace(const Layout& lo, int B, int T, int S, int cond_rows,
   size_t o = 0;
   auto take = [&](size_t n) { size_t r = o; o = align64(o + n); return r; };
   w->h = take((size_t)B * w->Tp * H);
-  w->q = take((size_t)B * w->Tp * H);
-  w->k = take((size_t)B * w->Tp * H);
-  w->vT = take((size_t)B * w->VR * w->Tp);
+  w->q = take((size_t)2 * B * w->Tp * H);  // two sets each (ping-pong between layers)
+  w->k = take((size_t)2 * B * w->Tp * H);
+  w->vT = take((size_t)2 * B * w->VR * w->Tp);
   w->kc = take((size_t)lo.L * B * w->Sp * H);
   w->vcT = take((size_t)lo.L * B * w->VR * w->Sp);
   w->cond = take((size_t)cond_rows * lo.L * 2 * 2 * H + (size_t)cond_rows * H);  // AdaLN rows + t_cond scratch
@@ -930,7 +935,7 @@ struct Launcher {
     memset(a, 0, sizeof(*a));
     a->B = B; a->T = T; a->Tp = ws.Tp; a->S = S; a->Sp = ws.Sp; a->window = window; a->max_pos = lo.MAXPOS;
     a->max_cpos = lo.MAXCPOS; a->n_tok = lo.NTOK; a->SD = lo.SD; a->L = lo.L;
-    a->h = wsb + ws.h; a->q = wsb + ws.q; a->k = wsb + ws.k; a->vT = wsb + ws.vT;
+    a->h = wsb + ws.h;
     a->inp = blob + lo.inp; a->inp_b = blob + lo.inp_b; a->pe = blob + lo.pe;
     a->fnw = blob + lo.fnw; a->fnb = blob + lo.fnb; a->outp_b = blob + lo.outp_b;
 #ifdef EDTTS_DIAG
@@ -957,12 +962,19 @@ struct Launcher {
     base_args(lo, blob, ws, wsb, B, T, S, window, &a);
     a.x = x; a.cond = cond_row; a.cond_bstride = cond_bstride;
     const int g = grid(B, ws.Tp);
+    const size_t qk_set = (size_t)B * ws.Tp * lo.H, v_set = (size_t)B * ws.VR * ws.Tp;
+    auto set_qkv = [&](int in_set, int out_set) {
+      a.q = wsb + ws.q + in_set * qk_set; a.k = wsb + ws.k + in_set * qk_set; a.vT = wsb + ws.vT + in_set * v_set;
+      a.q_out = wsb + ws.q + out_set * qk_set; a.k_out = wsb + ws.k + out_set * qk_set; a.vT_out = wsb + ws.vT + out_set * v_set;
+    };
+    set_qkv(1, 0);  // the prologue writes set 0
     a.n1w = blob + lo.layer[0].n1w; a.stream = blob + lo.layer[0].s_qkv; a.layer = 0;
     hipLaunchKernelGGL(k_prologue<C>, dim3(g), dim3(C::THREADS), ring_lds(), st, a);
     LAUNCH_CHECK("k_prologue");
     for (int l = 0; l < lo.L; ++l) {
       const LayerLayout& y = lo.layer[l];
       a.layer = l;
+      set_qkv(l & 1, (l + 1) & 1);  // layer l reads set l%2 and its QKV tail writes set (l+1)%2
       a.proj_b = blob + y.proj_b; a.n2w = blob + y.n2w; a.n3w = blob + y.n3w; a.up_b = blob + y.up_b;
       a.down_b = blob + y.down_b; a.stream = blob + y.s_body;
       a.kc = wsb + ws.kc + (size_t)l * B * ws.Sp * lo.H;

@@ -72,7 +72,7 @@ int edtts_packed_bytes(const EdttsDims* dims, size_t* out_bytes);
 int edtts_pack_weights(const EdttsDims* dims, const void* const* slots, int n_slots, void* packed, void* stream);
 
 /* ---- workspace ----------------------------------------------------------------------------------------
- * Scratch for activations (h, q, k, v^T), the per-call cross-attention K/V cache and the AdaLN rows.
+ * Scratch for activations (h, two ping-pong sets of q, k, v^T), the per-call cross-attention K/V cache and the AdaLN rows.
  * cond_rows = number of (t, step_idx) rows the conditioning kernel is run for (B for a plain forward,
  * num_steps for the fused sampler).  The workspace must be ZERO-FILLED once after allocation (padding
  * lanes are read but never written) and may then be reused for any number of calls of the same shape. */

@@ -473,3 +473,23 @@ def test_dpm_solver_pp(golden):
     assert max_abs(fused, x) < 2e-5
     with pytest.raises((IndexError, RuntimeError)):
         solver.sample(dec, cu(g["x_T"]), cu(g["sem_features"]), num_steps=17)
+
+
+def test_no_cross_block_hazard_when_utterances_straddle_block_rounds():
+    """Regression test for a write-after-read hazard between blocks of ONE layer launch: the QKV tail writes the next layer's
+    K / V^T while later-scheduled neighbouring blocks still need this layer's halo rows.  T = 768 gives 6 blocks per utterance
+    and B = 64 gives 384 blocks; with the XCD-aware remap each XCD owns 48 consecutive tiles of which 32 are resident first, so
+    the utterances covering tiles x*48+31 | x*48+32 (utterances 5, 13, 21, ...) have blocks in both batches.  q / k / v^T
+    therefore ping-pong between two buffer sets.  Every utterance of the big batch must equal the same utterance run alone."""
+    cfg = CFG(device=DEV)
+    dec = make_decoder(cfg, 0)
+    gen = torch.Generator().manual_seed(21)
+    B, S = 64, 384
+    x = torch.randn(B, 2 * S, 80, generator=gen).to(DEV)
+    sem = torch.randint(0, 512, (B, S), generator=gen).to(DEV)
+    t = torch.full((B,), 600, device=DEV)
+    si = torch.full((B,), 1, device=DEV)
+    big = dec(x, t, sem, si)
+    for u in (0, 5, 13, 21, 29, 37, 45, 53, 61, 63):
+        solo = dec(x[u:u + 1].contiguous(), t[:1], sem[u:u + 1].contiguous(), si[:1])
+        assert torch.equal(solo[0], big[u]), u
