@@ -336,8 +336,7 @@ EDTTS_DEV int remap_block(int bid, int nblk) {
 
 struct TileId {
   int b, m0;
-  bool valid;  // false: a padding wave of the last block -- it recomputes the last tile (keeps the block's barriers
-               // balanced) and must not store anything
+  bool valid;  // false: a padding wave of the last block (no block-level synchronisation in these kernels: it just exits)
 };
 EDTTS_DEV TileId wave_tile(int B, int Tp, int waves_per_block, int wave_frames) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -389,6 +388,7 @@ template <class C>
 __global__ __launch_bounds__(C::THREADS) void k_prologue(KArgs a) {
   constexpr int NF = C::NF;
   const TileId tl = wave_tile(a.B, a.Tp, C::WAVES, C::WF);
+  if (!tl.valid) return;
   const int lane = threadIdx.x & 63, fq = lane & 15, g = lane >> 4;
   const int b = tl.b, m0 = tl.m0;
   WStream<C> ring;
@@ -462,6 +462,7 @@ __global__ __launch_bounds__(C::THREADS) void k_layer(KArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int NF = C::NF;
   const TileId tl = wave_tile(a.B, a.Tp, C::WAVES, C::WF);
+  if (!tl.valid) return;
   const int lane = threadIdx.x & 63, fq = lane & 15, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int b = tl.b, m0 = tl.m0;
