@@ -97,6 +97,10 @@ EDTTS_DEV float hmax(f4 v) { return fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
 // the top of each phase (measured 126 -> 137 TFLOP/s on the bare stream).  The sched_barrier pins the issue point:
 // without it the pre-RA scheduler sinks each load to its use RN fragments later, i.e. load -> s_waitcnt -> MFMA.
 // ---------------------------------------------------------------------------------------------------------
+#ifndef EDTTS_RB
+#define EDTTS_RB 4
+#endif
+constexpr int kRefillBurst = EDTTS_RB;
 template <int RN>
 struct FragRing {
   const f4* p;  // lane-offset pointer to position 0 of the current phase
@@ -107,9 +111,19 @@ struct FragRing {
     for (int i = 0; i < RN; ++i) r[i] = p[i * 64];
   }
   EDTTS_DEV const f4& at(int i) const { return r[i % RN]; }
-  EDTTS_DEV void refill(int i) {
-    r[i % RN] = p[(i + RN) * 64];
+  // Refill the slots of positions [lo, hi) (all consumed) in ONE burst.  Every interruption of the MFMA stream by VMEM
+  // issue costs ~20 cycles plus ~3 per load (scratch/mfma_probe3.cpp), so the loads go out kRefillBurst at a time.
+  EDTTS_DEV void refill(int lo, int hi) {
+#pragma unroll
+    for (int i = lo; i < hi; ++i) r[i % RN] = p[(i + RN) * 64];
     __builtin_amdgcn_sched_barrier(0);
+  }
+  // called after position i of an N-fragment phase has been consumed
+  template <int N>
+  EDTTS_DEV void refill_after(int i) {
+    constexpr int B = kRefillBurst < RN ? kRefillBurst : RN;
+    if ((i + 1) % B == 0) refill(i + 1 - B, i + 1);
+    else if (i == N - 1) refill(N - N % B, N);
   }
   EDTTS_DEV void advance(int n) { p += n * 64; }
 };
@@ -136,7 +150,7 @@ EDTTS_DEV void gemm_phase(FragRing<RN>& ring, const f4 (&in)[KT][NF], f4 (&acc)[
         if (SPLIT && (kt & 1)) b[ft] = EDTTS_MFMA(a[r], in[kt][ft][r], b[ft]);
         else acc[ft] = EDTTS_MFMA(a[r], in[kt][ft][r], acc[ft]);
       }
-    ring.refill(kt);
+    ring.template refill_after<KT>(kt);
   }
   if (SPLIT) {
 #pragma unroll
@@ -161,8 +175,8 @@ EDTTS_DEV void gemm_phase_pair(FragRing<RN>& ring, const f4 (&in)[KT][NF], f4 (&
 #pragma unroll
       for (int ft = 0; ft < NF; ++ft) b[ft] = EDTTS_MFMA(fb[r], in[kt][ft][r], b[ft]);
     }
-    ring.refill(2 * kt);
-    ring.refill(2 * kt + 1);
+    ring.template refill_after<2 * KT>(2 * kt);
+    ring.template refill_after<2 * KT>(2 * kt + 1);
   }
   ring.advance(2 * KT);
 }
@@ -186,7 +200,7 @@ EDTTS_DEV void ktile_phase(FragRing<RN>& ring, const f4 (&in)[NF], f4 (&acc)[NT]
         }
 #pragma unroll
     for (int u = 0; u < STEP; ++u)
-      if (nt + u < NT) ring.refill(nt + u);
+      if (nt + u < NT) ring.template refill_after<NT>(nt + u);
   }
   ring.advance(NT);
 }
@@ -265,6 +279,9 @@ EDTTS_DEV float silu(float g) { return g * __builtin_amdgcn_rcpf(1.0f + __expf(-
 // Ring size: HT fragments at NF = 2, HT/2 at NF = 4 -- the same prefetch distance in MFMAs (4*NF per fragment).
 template <class C> using WStream = FragRing<((C::HT * 2) / C::NF >= 2 && C::HT % ((C::HT * 2) / C::NF) == 0 ? (C::HT * 2) / C::NF : C::HT)>;
 
+#ifndef EDTTS_ACLUMP
+#define EDTTS_ACLUMP 1
+#endif
 constexpr int kChunk = 2;  // key tiles (16 keys each) per online-softmax step
 constexpr float kDefer = 32.f;  // octaves a chunk may exceed the softmax reference point before it is moved
 
@@ -360,40 +377,60 @@ EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, cons
     }
   };
   // Mask of chunk c as the INITIAL accumulator of its K Q^T product: 0 where the key is visible, -inf elsewhere
-  // (-inf + finite products = -inf).  Computed before the MFMAs are issued, so no VALU work sits between the MFMA
-  // results and the softmax; interior chunks (every key inside the band of every query of the half and below klim: 3 of
-  // the 5 chunks at window 64, all of the cross-attention when S % 32 == 0) take the wave-uniform zero path.
-  auto mask_init = [&](const Geo& q, int c, f4 (&S)[CH][2]) {
+  // (-inf + finite products = -inf), so no VALU work sits between the MFMA results and the softmax.  Interior chunks (every
+  // key inside the band of every query of the half and below klim: 3 of the 5 chunks at window 64, all of the cross-attention
+  // when S % 32 == 0) take a wave-uniform path whose first MFMA of each chain has the inline constant 0 as accumulator input:
+  // no mask arithmetic and no accumulator initialisation at all (32 VALU instructions per chunk less).
+  auto chunk_is_interior = [&](const Geo& q, int c) {
     c = c < q.nchunk ? c : q.nchunk - 1;
     const int k0 = (q.kt_lo + c * CH) << 4, k1 = k0 + 16 * CH - 1;
     bool full = k1 < q.klim && (q.kt_lo + (c + 1) * CH) <= q.kt_hi;
     if (SELF && window >= 0) full = full && (k1 - q.m0 <= window) && (k0 - (q.m0 + 31) >= -window);
+    return full;
+  };
+  auto mask_init = [&](const Geo& q, int c, f4 (&S)[CH][2]) {
+    c = c < q.nchunk ? c : q.nchunk - 1;
+    const int k0 = (q.kt_lo + c * CH) << 4;
 #pragma unroll
-    for (int t = 0; t < CH; ++t) S[t][0] = S[t][1] = splat(0.f);
-    if (!full) {
+    for (int ft = 0; ft < 2; ++ft) {
+      const int d0 = k0 + 4 * g - (q.m0 + 16 * ft + fq) - q.lo_d[ft];  // (key - query - lo_d) of r = 0, tile 0
+      const unsigned sp = q.span[ft] >= 0 ? (unsigned)q.span[ft] : 0u;
+      const int bias = q.span[ft] >= 0 ? 0 : (1 << 30);                 // nothing valid for this query
 #pragma unroll
-      for (int ft = 0; ft < 2; ++ft) {
-        const int d0 = k0 + 4 * g - (q.m0 + 16 * ft + fq) - q.lo_d[ft];  // (key - query - lo_d) of r = 0, tile 0
-        const unsigned sp = q.span[ft] >= 0 ? (unsigned)q.span[ft] : 0u;
-        const int bias = q.span[ft] >= 0 ? 0 : (1 << 30);                 // nothing valid for this query
+      for (int t = 0; t < CH; ++t)
 #pragma unroll
-        for (int t = 0; t < CH; ++t)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) S[t][ft][r] = (unsigned)(d0 + bias + 16 * t + r) <= sp ? 0.f : NEG_INF;
-      }
+        for (int r = 0; r < 4; ++r) S[t][ft][r] = (unsigned)(d0 + bias + 16 * t + r) <= sp ? 0.f : NEG_INF;
     }
   };
-  // S^T chunk += K Q^T for both query tiles, accumulators interleaved (2*CH independent chains)
-  auto qk = [&](const KVFrag<C>& f, const f4 (&qa)[2][DFULL > 0 ? DFULL : 1], const f2 (&qr)[2], f4 (&S)[CH][2]) {
+  // S^T chunk = mask + K Q^T for both query tiles, accumulators interleaved (2*CH independent chains)
+  auto qk = [&](const Geo& q, int c, const KVFrag<C>& f, const f4 (&qa)[2][DFULL > 0 ? DFULL : 1], const f2 (&qr)[2],
+                f4 (&S)[CH][2]) {
+    static_assert(DFULL >= 1, "head_dim >= 16 expected");
+    if (chunk_is_interior(q, c)) {
+#pragma unroll
+      for (int t = 0; t < CH; ++t) {
+        S[t][0] = EDTTS_MFMA(f.ka[t][0][0], qa[0][0][0], splat(0.f));
+        S[t][1] = EDTTS_MFMA(f.ka[t][0][0], qa[1][0][0], splat(0.f));
+      }
+    } else {
+      mask_init(q, c, S);
+#pragma unroll
+      for (int t = 0; t < CH; ++t) {
+        S[t][0] = EDTTS_MFMA(f.ka[t][0][0], qa[0][0][0], S[t][0]);
+        S[t][1] = EDTTS_MFMA(f.ka[t][0][0], qa[1][0][0], S[t][1]);
+      }
+    }
 #pragma unroll
     for (int a = 0; a < DFULL; ++a)
 #pragma unroll
-      for (int b = 0; b < 4; ++b)
+      for (int b = 0; b < 4; ++b) {
+        if (a == 0 && b == 0) continue;
 #pragma unroll
         for (int t = 0; t < CH; ++t) {
           S[t][0] = EDTTS_MFMA(f.ka[t][a][b], qa[0][a][b], S[t][0]);
           S[t][1] = EDTTS_MFMA(f.ka[t][a][b], qa[1][a][b], S[t][1]);
         }
+      }
     if (DREM) {
 #pragma unroll
       for (int b = 0; b < 2; ++b)
@@ -468,7 +505,10 @@ EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, cons
 #endif
         __builtin_amdgcn_sched_barrier(0);
         // scores of the NEXT chunk: independent MFMA work that overlaps this chunk's softmax VALU (same scheduling region)
-        if (decltype(has_next)::value) qk(Kuse, qa, qr, Sn);
+        if (decltype(has_next)::value) qk(q, c + 1, Kuse, qa, qr, Sn);
+#if EDTTS_ACLUMP
+        __builtin_amdgcn_sched_barrier(0);  // MFMA run | VALU clump | MFMA run: every switch costs ~8 cycles (mfma_probe3)
+#endif
 #ifdef EDTTS_ABLATE_SOFTMAX  // timing ablation only: P = S (no max, no exp, no rescale); results are wrong by construction
         f4 P[CH][2];
 #pragma unroll
@@ -511,6 +551,9 @@ EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, cons
           }
         }
 #endif
+#if EDTTS_ACLUMP
+        __builtin_amdgcn_sched_barrier(0);
+#endif
         // O^T += V^T P^T : DT x 2 independent accumulators, r outermost
 #pragma unroll
         for (int t = 0; t < CH; ++t)
@@ -524,19 +567,15 @@ EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, cons
       };
 
       f4 SA[CH][2], SB[CH][2];
-      mask_init(q, 0, SA);
-      qk(KA, qa, qr, SA);  // scores of chunk 0; KB holds chunk 1, VA chunk 0
+      qk(q, 0, KA, qa, qr, SA);  // scores of chunk 0; KB holds chunk 1, VA chunk 0
       using Yes = std::integral_constant<bool, true>;
       using No = std::integral_constant<bool, false>;
       int c = 0;
       for (; c + 2 < nchunk; c += 2) {
-        mask_init(q, c + 1, SB);
         step(Yes{}, c, SA, SB, KB, KA, VA, VB);      // finishes chunk c; scores of c+1 -> SB (from KB); loads K(c+2) -> KA, V(c+1) -> VB
-        mask_init(q, c + 2, SA);
         step(Yes{}, c + 1, SB, SA, KA, KB, VB, VA);  // finishes chunk c+1; scores of c+2 -> SA (from KA); loads K(c+3) -> KB, V(c+2) -> VA
       }
       if (nchunk - c == 2) {  // two chunks left: scores of c are in SA, V(c) in VA
-        mask_init(q, c + 1, SB);
         step(Yes{}, c, SA, SB, KB, KA, VA, VB);
         step(No{}, c + 1, SB, SA, KA, KB, VB, VA);
       } else {                // one chunk left

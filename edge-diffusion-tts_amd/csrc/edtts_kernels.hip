@@ -457,6 +457,9 @@ struct QLds {  // q tile in this wave's LDS region, [32][QLD]
 // layer, which buys the FFN / QKV weight stream twice the MFMAs per fragment without inflating the attention's registers.
 enum { PART_ALL = 0, PART_ATTN = 1, PART_FFN = 2 };
 
+#ifndef EDTTS_GCLUMP
+#define EDTTS_GCLUMP 1
+#endif
 template <class C, int TAIL, int PART>
 __global__ __launch_bounds__(C::THREADS) void k_layer(KArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -540,13 +543,28 @@ __global__ __launch_bounds__(C::THREADS) void k_layer(KArgs a) {
 #pragma unroll
       for (int ft = 0; ft < NF; ++ft) v[ft] = gt[ft] = splat(0.f);
       gemm_phase_pair<C::HT>(ring, hn, v, gt);
+#if EDTTS_GCLUMP
+      __builtin_amdgcn_sched_barrier(0);  // one VALU clump between the two MFMA phases: every MFMA<->VALU switch costs ~8 cycles
+#endif
 #pragma unroll
       for (int ft = 0; ft < NF; ++ft) {
         v[ft] += vb;  // bias after the GEMM: its load is off the MFMA critical path
         gt[ft] += gb;
+#if EDTTS_GCLUMP
+        // SwiGLU: value * silu(gate) (transformer.py:21-23), written on vectors so that the mul / add halves pack (v_pk_*)
+        const f4 e = {fast_exp2(gt[ft][0] * -1.4426950408889634f), fast_exp2(gt[ft][1] * -1.4426950408889634f),
+                      fast_exp2(gt[ft][2] * -1.4426950408889634f), fast_exp2(gt[ft][3] * -1.4426950408889634f)};
+        const f4 d = e + 1.0f;
+        const f4 rc = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1]), __builtin_amdgcn_rcpf(d[2]), __builtin_amdgcn_rcpf(d[3])};
+        act[ft] = (v[ft] * gt[ft]) * rc;
+#else
 #pragma unroll
         for (int r = 0; r < 4; ++r) act[ft][r] = v[ft][r] * silu(gt[ft][r]);  // SwiGLU: value * silu(gate), transformer.py:21-23
+#endif
       }
+#if EDTTS_GCLUMP
+      __builtin_amdgcn_sched_barrier(0);
+#endif
       ktile_phase<C::HT>(ring, act, h);
     }
   }
@@ -875,6 +893,9 @@ struct Workspace {
 // Measured at B=256, T=512 with -DEDTTS_NF_FFN=4: the 64-frame FFN half alone reaches 121.6 TFLOP/s (77 % of peak) against
 // ~80 % MFMA-busy inside the fused kernel, but attention half 0.613 ms + FFN half 0.462 ms = 1.075 ms per layer loses to the
 // fused 1.046 ms: the second kernel's start-up (exposed loads of 4096 waves at once) and drain cost more than the stream gains.
+#ifndef EDTTS_GCLUMP
+#define EDTTS_GCLUMP 1
+#endif
 #ifndef EDTTS_NF_FFN
 #define EDTTS_NF_FFN 0
 #endif
