@@ -103,6 +103,7 @@ EDTTS_DEV float hmax(f4 v) { return fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
 constexpr int kRefillBurst = EDTTS_RB;
 template <int RN>
 struct FragRing {
+  static constexpr int RN_ = RN;
   const f4* p;  // lane-offset pointer to position 0 of the current phase
   f4 r[RN];
   EDTTS_DEV void prime(const float* base, int lane) {
@@ -183,14 +184,15 @@ EDTTS_DEV void gemm_phase_pair(FragRing<RN>& ring, const f4 (&in)[KT][NF], f4 (&
 
 // acc[nt] += frag(nt) * in   for one k-tile of a k-major packed matrix (NT fragments).  At NF = 2 two n-tiles are
 // interleaved so that four accumulator chains are in flight.
-template <int NT, int RN, int NF>
+// NR < 4 issues only the first NR of the k-tile's MFMA steps (the remaining weights of the fragments are zero by packing).
+template <int NT, int RN, int NF, int NR = 4>
 EDTTS_DEV void ktile_phase(FragRing<RN>& ring, const f4 (&in)[NF], f4 (&acc)[NT][NF]) {
   static_assert(NT % RN == 0, "phase length must be a multiple of the ring size");
   constexpr int STEP = NF < 4 ? 2 : 1;
 #pragma unroll
   for (int nt = 0; nt < NT; nt += STEP) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
+    for (int r = 0; r < NR; ++r)
 #pragma unroll
       for (int u = 0; u < STEP; ++u)
         if (nt + u < NT) {
@@ -318,6 +320,10 @@ EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, cons
   // softmax in base 2: p = 2^((s - m) * c), c = log2(e) / sqrt(d)
   const float c2 = 1.4426950408889634f * rsqrtf((float)DH);
   const float NEG_INF = -__builtin_inff();
+  // Row map of the 8-feature remainder tile of V^T (head_dim % 16 == 8): MFMA row i = 4*gO + reg of the P V product carries
+  // feature 2*gO + reg for reg < 2 (rows with reg >= 2 repeat a valid row and are never read), so the valid features of O^T land
+  // in C/D registers 0 and 1 of every lane group and the output projection skips MFMA steps 2 and 3 of that k-tile.
+  const int vrow_rem = 2 * (fq >> 2) + (fq & 1);
 
   // per-half geometry (a half = 32 query frames starting at m0 = m0w + 32*half)
   struct Geo {
@@ -373,7 +379,7 @@ EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, cons
       int kt = q.kt_lo + c * CH + t;
       kt = kt < q.kt_hi ? kt : q.kt_hi - 1;
 #pragma unroll
-      for (int dt = 0; dt < DT; ++dt) f.v[t][dt] = ldg4(VTb + (size_t)(hd * DH + 16 * dt + fq) * ldv + (kt << 4) + 4 * g);
+      for (int dt = 0; dt < DT; ++dt) f.v[t][dt] = ldg4(VTb + (size_t)(hd * DH + 16 * dt + ((DREM && dt == DT - 1) ? vrow_rem : fq)) * ldv + (kt << 4) + 4 * g);
     }
   };
   // Mask of chunk c as the INITIAL accumulator of its K Q^T product: 0 where the key is visible, -inf elsewhere
@@ -593,7 +599,10 @@ EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, cons
     // ---- project: h[nt] += Wo[:, head features] . O  (all NF frame tiles at once) ------------------------------------
     if (hd + 1 < C::HEADS) prefetch(geo[0], hd + 1, 0);
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt) ktile_phase<C::HT>(ring, O[dt], h);
+    for (int dt = 0; dt < DT; ++dt) {
+      if (DREM && dt == DT - 1) ktile_phase<C::HT, WStream<C>::RN_, NF, 2>(ring, O[dt], h);  // remainder tile: valid k in steps 0, 1 only
+      else ktile_phase<C::HT>(ring, O[dt], h);
+    }
   }
 }
 

@@ -161,7 +161,7 @@ struct PackArgs {
   int ld, N, K;      // source row stride, logical rows / cols
   int NT, KT;        // packed tile counts
   int rowmode;       // 0 identity, 1 ffn-up interleave (tile 2j = value rows 16j.., tile 2j+1 = gate rows N/2+16j..)
-  int colmode;       // 0 identity, 1 head padding (packed col hd*DHP+dd <- hd*DH+dd, zero for dd >= DH)
+  int colmode;       // 0 identity, 1 head padding (packed col hd*DHP+dd <- hd*DH+dd; the 8-wide remainder tile is permuted, see k_pack_gemm)
   int dstmode;       // 0 n-major, 1 k-major, 2 ffn-up inside the ffn stream, 3 ffn-down inside the ffn stream
   int DH, DHP;
   float* dst;
@@ -187,8 +187,17 @@ __global__ void k_pack_gemm(PackArgs a) {
     bool cok = k < a.K;
     if (a.colmode == 1) {
       const int hd = k / a.DHP, dd = k % a.DHP;
-      cok = dd < a.DH;
-      col = hd * a.DH + dd;
+      const int full = a.DH & ~15;  // features covered by whole 16-wide k-tiles
+      if (dd < full) {
+        cok = true;
+        col = hd * a.DH + dd;
+      } else {
+        // the 8-feature remainder tile: feature full + 2g + r sits at (lane group g, MFMA step r) for r < 2, so that the
+        // projection only issues 2 of the tile's 4 MFMA steps (edtts_device.h: attention_fused, kRemSteps)
+        const int kk = dd - full;  // = 4g + r
+        cok = (kk & 3) < 2 && full + 2 * (kk >> 2) + (kk & 3) < a.DH;
+        col = hd * a.DH + full + 2 * (kk >> 2) + (kk & 3);
+      }
     }
     v[r] = (rok && cok) ? a.src[(size_t)row * a.ld + col] : 0.f;
   }
