@@ -364,32 +364,36 @@ EDTTS_DEV TileId wave_tile(int B, int Tp, int waves_per_block, int wave_frames) 
 // (layers/attention.py:91-93: rows of qkv.weight are q | k | v, each head-major)
 // ---------------------------------------------------------------------------------------------------------
 template <class C>
-EDTTS_DEV void qkv_tail(WStream<C>& ring, const f4 (&hn)[C::HT][C::NF], const KArgs& a, int b, int m0, int lane, bool valid) {
+EDTTS_DEV void qkv_tail(WStream<C>& ring, const f4 (&hn)[C::HT][C::NF], const KArgs& a, int b, int m0, int lane) {
   constexpr int NF = C::NF;
   const int fq = lane & 15, g = lane >> 4;
   const size_t rowbase = (size_t)b * a.Tp + m0 + fq;
+  // One loop per output so that the number of stores between two ring waits is a compile-time fact of each loop: the
+  // s_waitcnt pass sizes vmcnt(N) for the path with the FEWEST later memory operations, and on gfx9 stores count in vmcnt
+  // too -- with the q/k/v^T cases (2 / 2 / 8 stores) behind run-time branches of one loop it emitted vmcnt(9), which on the
+  // v^T path forces eight more ring loads to have landed than necessary (the stores ate the prefetch depth).
+#pragma unroll
   for (int which = 0; which < 3; ++which) {
     for (int nt = 0; nt < C::HT; ++nt) {
       f4 acc[NF];
 #pragma unroll
       for (int ft = 0; ft < NF; ++ft) acc[ft] = splat(0.f);
       gemm_phase<C::HT>(ring, hn, acc);
-      if (!valid) continue;
+#ifdef EDTTS_ABLATE_QKVSTORES  // timing ablation only (results wrong by construction)
+      if (a.T > 0) continue;
+#endif
+      // streaming stores: the q / k / v^T rows are consumed by the NEXT launch; measured 0.3 % faster than plain stores
       if (which < 2) {
         float* dst = (which == 0 ? a.q_out : a.k_out) + rowbase * C::H + 16 * nt + 4 * g;
 #pragma unroll
-        for (int ft = 0; ft < NF; ++ft) {
-          // streaming stores: the q / k / v^T rows are consumed by the NEXT launch; measured 0.3 % faster than plain stores
+        for (int ft = 0; ft < NF; ++ft)
           __builtin_nontemporal_store(acc[ft], reinterpret_cast<f4*>(dst + (size_t)ft * 16 * C::H));
-        }
       } else {
         float* dst = a.vT_out + ((size_t)b * C::VR + 16 * nt + 4 * g) * a.Tp + m0 + fq;
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
-          for (int ft = 0; ft < NF; ++ft) {
-            __builtin_nontemporal_store(acc[ft][r], dst + (size_t)r * a.Tp + 16 * ft);
-          }
+          for (int ft = 0; ft < NF; ++ft) __builtin_nontemporal_store(acc[ft][r], dst + (size_t)r * a.Tp + 16 * ft);
       }
     }
   }
@@ -445,7 +449,7 @@ __global__ __launch_bounds__(C::THREADS) void k_prologue(KArgs a) {
   f4 hn[C::HT][NF];
   const float* mod = a.cond + (size_t)b * a.cond_bstride;  // layer 0, norm1
   rms_norm_tile<C::HT, NF>(h, a.n1w, mod, g, hn);
-  qkv_tail<C>(ring, hn, a, b, m0, lane, tl.valid);
+  qkv_tail<C>(ring, hn, a, b, m0, lane);
 }
 
 // =========================================================================================================
@@ -595,7 +599,7 @@ __global__ __launch_bounds__(C::THREADS) void k_layer(KArgs a) {
     // h has been stored: normalise in place (the function is alias-safe) instead of keeping a second 16*NF*HT-register tile
     const float* mod = a.cond + (size_t)b * a.cond_bstride + ((size_t)(a.layer + 1) * 2) * 2 * C::H;
     rms_norm_tile<C::HT, NF>(h, a.n1w, mod, g, h);
-    qkv_tail<C>(ring, h, a, b, m0, lane, tl.valid);
+    qkv_tail<C>(ring, h, a, b, m0, lane);
   } else {
     f4 hn[C::HT][NF];
     layer_norm_tile<C::HT, NF>(h, a.fnw, a.fnb, g, hn);
