@@ -206,6 +206,7 @@ __global__ void k_pack_gemm(PackArgs a) {
   switch (a.dstmode) {
     case 0: frag = (size_t)nt * a.KT + kt; break;
     case 1: frag = (size_t)kt * a.NT + nt; break;
+    case 4: frag = (size_t)(nt >> 1) * (2 * a.KT) + 2 * kt + (nt & 1); break;           // n-tile pairs interleaved per k-tile (gemm_phase_pair)
     case 2: frag = (size_t)(nt >> 1) * (3 * a.KT) + 2 * kt + (nt & 1); break;           // up: [j][kt][value | gate], then down NT
     default: frag = (size_t)kt * (3 * a.NT) + 2 * a.NT + nt; break;                       // down: k-tile kt = hidden tile j
   }
@@ -366,6 +367,7 @@ EDTTS_DEV TileId wave_tile(int B, int Tp, int waves_per_block, int wave_frames) 
 template <class C>
 EDTTS_DEV void qkv_tail(WStream<C>& ring, const f4 (&hn)[C::HT][C::NF], const KArgs& a, int b, int m0, int lane) {
   constexpr int NF = C::NF;
+  static_assert(C::HT % 2 == 0, "hidden must be a multiple of 32 (n-tile pairs)");
   const int fq = lane & 15, g = lane >> 4;
   const size_t rowbase = (size_t)b * a.Tp + m0 + fq;
   // One loop per output so that the number of stores between two ring waits is a compile-time fact of each loop: the
@@ -374,26 +376,30 @@ EDTTS_DEV void qkv_tail(WStream<C>& ring, const f4 (&hn)[C::HT][C::NF], const KA
   // v^T path forces eight more ring loads to have landed than necessary (the stores ate the prefetch depth).
 #pragma unroll
   for (int which = 0; which < 3; ++which) {
-    for (int nt = 0; nt < C::HT; ++nt) {
-      f4 acc[NF];
+    for (int nt = 0; nt < C::HT; nt += 2) {
+      // two n-tiles per phase (pair-interleaved stream): four accumulator chains without the split-K sum of gemm_phase
+      f4 acc[2][NF];
 #pragma unroll
-      for (int ft = 0; ft < NF; ++ft) acc[ft] = splat(0.f);
-      gemm_phase<C::HT>(ring, hn, acc);
+      for (int ft = 0; ft < NF; ++ft) acc[0][ft] = acc[1][ft] = splat(0.f);
+      gemm_phase_pair<C::HT>(ring, hn, acc[0], acc[1]);
 #ifdef EDTTS_ABLATE_QKVSTORES  // timing ablation only (results wrong by construction)
       if (a.T > 0) continue;
 #endif
       // streaming stores: the q / k / v^T rows are consumed by the NEXT launch; measured 0.3 % faster than plain stores
-      if (which < 2) {
-        float* dst = (which == 0 ? a.q_out : a.k_out) + rowbase * C::H + 16 * nt + 4 * g;
 #pragma unroll
-        for (int ft = 0; ft < NF; ++ft)
-          __builtin_nontemporal_store(acc[ft], reinterpret_cast<f4*>(dst + (size_t)ft * 16 * C::H));
-      } else {
-        float* dst = a.vT_out + ((size_t)b * C::VR + 16 * nt + 4 * g) * a.Tp + m0 + fq;
+      for (int u = 0; u < 2; ++u) {
+        if (which < 2) {
+          float* dst = (which == 0 ? a.q_out : a.k_out) + rowbase * C::H + 16 * (nt + u) + 4 * g;
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
+          for (int ft = 0; ft < NF; ++ft)
+            __builtin_nontemporal_store(acc[u][ft], reinterpret_cast<f4*>(dst + (size_t)ft * 16 * C::H));
+        } else {
+          float* dst = a.vT_out + ((size_t)b * C::VR + 16 * (nt + u) + 4 * g) * a.Tp + m0 + fq;
 #pragma unroll
-          for (int ft = 0; ft < NF; ++ft) __builtin_nontemporal_store(acc[ft][r], dst + (size_t)r * a.Tp + 16 * ft);
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int ft = 0; ft < NF; ++ft) __builtin_nontemporal_store(acc[u][ft][r], dst + (size_t)r * a.Tp + 16 * ft);
+        }
       }
     }
   }
@@ -439,7 +445,7 @@ __global__ __launch_bounds__(C::THREADS) void k_prologue(KArgs a) {
         for (int ft = 0; ft < NF; ++ft) h[nt][ft] = EDTTS_MFMA(w[r], xin[kt][ft][r], h[nt][ft]);
     }
   }
-  if (tl.valid) {
+  {  // (padding waves have returned)
     float* hp = a.h + ((size_t)b * a.Tp + m0 + fq) * C::H + 4 * g;
 #pragma unroll
     for (int nt = 0; nt < C::HT; ++nt)
@@ -520,13 +526,15 @@ __global__ __launch_bounds__(C::THREADS) void k_layer(KArgs a) {
   if (PART != PART_FFN && DIAG_ON(2)) {
     f4 hn[C::HT][NF];
     rms_norm_tile<C::HT, NF>(h, a.n2w, nullptr, g, hn);
-    for (int nt = 0; nt < C::HT; ++nt) {
-      f4 acc[NF];
+    for (int nt = 0; nt < C::HT; nt += 2) {
+      f4 acc[2][NF];
 #pragma unroll
-      for (int ft = 0; ft < NF; ++ft) acc[ft] = splat(0.f);
-      gemm_phase<C::HT>(ring, hn, acc);
+      for (int ft = 0; ft < NF; ++ft) acc[0][ft] = acc[1][ft] = splat(0.f);
+      gemm_phase_pair<C::HT>(ring, hn, acc[0], acc[1]);
 #pragma unroll
-      for (int ft = 0; ft < NF; ++ft) stg4(qtile + (16 * ft + fq) * C::QLD + 16 * nt + 4 * g, acc[ft]);
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int ft = 0; ft < NF; ++ft) stg4(qtile + (16 * ft + fq) * C::QLD + 16 * (nt + u) + 4 * g, acc[u][ft]);
     }
   }
   if (PART != PART_FFN && DIAG_ON(2)) {
@@ -535,7 +543,7 @@ __global__ __launch_bounds__(C::THREADS) void k_layer(KArgs a) {
                               ring, h);
   }
   if (PART == PART_ATTN) {  // hand the residual tile to the FFN half
-    if (tl.valid) {
+    {  // (padding waves have returned)
       float* hp = a.h + rowbase * C::H + 4 * g;
 #pragma unroll
       for (int nt = 0; nt < C::HT; ++nt)
@@ -589,7 +597,7 @@ __global__ __launch_bounds__(C::THREADS) void k_layer(KArgs a) {
   // ---- tail ---------------------------------------------------------------------------------------------------
   if (!DIAG_ON(8)) return;
   if (TAIL == TAIL_QKV) {
-    if (tl.valid) {
+    {  // (padding waves have returned)
       float* hp = a.h + rowbase * C::H + 4 * g;
 #pragma unroll
       for (int nt = 0; nt < C::HT; ++nt)
@@ -613,7 +621,7 @@ __global__ __launch_bounds__(C::THREADS) void k_layer(KArgs a) {
 #pragma unroll
       for (int ft = 0; ft < NF; ++ft) {
         const int f = m0 + 16 * ft + fq;
-        if (f >= a.T || !tl.valid) continue;
+        if (f >= a.T) continue;
         const size_t idx = ((size_t)b * a.T + f) * C::MEL + 16 * nt + 4 * g;
         const f4 ev = e[ft] + ob;
         if (TAIL == TAIL_EPS) {
@@ -1221,11 +1229,11 @@ int edtts_pack_weights(const EdttsDims* dims, const void* const* slots, int n_sl
     TRY(copy_f(st, W(L_KVN_W), blob + y.kvn, R));
     TRY(pack_gemm(st, W(L_KVU_W), R, 2 * H, R, 2 * HT, RT, 0, 0, 0, DH, DHP, blob + y.kvu));
     // fragment stream
-    TRY(pack_gemm(st, W(L_QKV_W), H, 3 * H, H, 3 * HT, HT, 0, 0, 0, DH, DHP, blob + y.s_qkv));
+    TRY(pack_gemm(st, W(L_QKV_W), H, 3 * H, H, 3 * HT, HT, 0, 0, 4, DH, DHP, blob + y.s_qkv));  // n-tile pairs
     float* s = blob + y.s_body;
     TRY(pack_gemm(st, W(L_PROJ_W), H, H, lo.HEADS * DHP, HT, KPT, 0, 1, 1, DH, DHP, s));
     s += (size_t)KPT * HT * kFrag;
-    TRY(pack_gemm(st, W(L_QP_W), H, H, H, HT, HT, 0, 0, 0, DH, DHP, s));
+    TRY(pack_gemm(st, W(L_QP_W), H, H, H, HT, HT, 0, 0, 4, DH, DHP, s));
     s += (size_t)HT * HT * kFrag;
     TRY(pack_gemm(st, W(L_OP_W), H, H, lo.HEADS * DHP, HT, KPT, 0, 1, 1, DH, DHP, s));
     s += (size_t)KPT * HT * kFrag;
