@@ -130,7 +130,7 @@ static int make_layout(const EdttsDims* d, Layout* lo) {
   lo->semp = take(HT * (SD / 16) * kFrag); lo->semp_b = take(H);
   lo->t1T = take(H * H); lo->t1b = take(H); lo->t3T = take(H * H); lo->t3b = take(H);
   lo->step = take((size_t)lo->NSTEP * H);
-  lo->inp = take(HT * MT * kFrag); lo->inp_b = take(H);
+  lo->inp_b = take(H);
   lo->pe = take((size_t)lo->MAXPOS * H); lo->cpe = take((size_t)lo->MAXCPOS * H);
   lo->fnw = take(H); lo->fnb = take(H); lo->outp_b = take(lo->MEL); lo->freqs = take(H / 2);
   for (int l = 0; l < lo->L; ++l) {
@@ -139,7 +139,8 @@ static int make_layout(const EdttsDims* d, Layout* lo) {
     y.n3w = take(H); y.ada3T = take(H * 2 * H); y.ada3b = take(2 * H); y.up_b = take(4 * H); y.down_b = take(H);
     y.kvd = take(RT * HT * kFrag); y.kvn = take(R); y.kvu = take(2 * HT * RT * kFrag);
   }
-  // contiguous fragment stream: qkv(0) body(0) qkv(1) body(1) ... body(L-1) outp  + one ring of slack
+  // contiguous fragment stream: inp qkv(0) body(0) qkv(1) body(1) ... body(L-1) outp  + one ring of slack
+  lo->inp = o; o += HT * MT * kFrag;  // in_proj, n-tile pairs: the prologue kernel streams inp | qkv(0)
   for (int l = 0; l < lo->L; ++l) {
     LayerLayout& y = lo->layer[l];
     y.s_qkv = o; o += 3 * HT * HT * kFrag;
@@ -425,8 +426,9 @@ __global__ __launch_bounds__(C::THREADS) void k_prologue(KArgs a) {
     for (int t = 0; t < C::MT; ++t)
       xin[t][ft] = f < a.T ? ldg4(a.x + ((size_t)b * a.T + f) * C::MEL + 16 * t + 4 * g) : splat(0.f);
   }
+  // h = in_proj(x) + bias + pe   (decoder.py:96-97).  The HT*MT in_proj fragments head the kernel's stream (n-tile pairs per
+  // k-tile) and are consumed as ONE ring phase, so they are prefetched like every other weight.
   f4 h[C::HT][NF];
-  const f4* wp = reinterpret_cast<const f4*>(a.inp) + lane;
 #pragma unroll
   for (int nt = 0; nt < C::HT; ++nt) {
     const f4 bias = ldg4(a.inp_b + 16 * nt + 4 * g);
@@ -436,14 +438,28 @@ __global__ __launch_bounds__(C::THREADS) void k_prologue(KArgs a) {
       f = f < a.max_pos ? f : a.max_pos - 1;
       h[nt][ft] = bias + ldg4(a.pe + (size_t)f * C::H + 16 * nt + 4 * g);  // embeddings.py:142
     }
+  }
+  {
+    constexpr int N = C::HT * C::MT;
+    static_assert(N % WStream<C>::RN_ == 0 && C::HT % 2 == 0, "in_proj must be a whole number of ring turns");
 #pragma unroll
-    for (int kt = 0; kt < C::MT; ++kt) {
-      const f4 w = wp[(nt * C::MT + kt) * 64];
+    for (int nt = 0; nt < C::HT; nt += 2)
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
+      for (int kt = 0; kt < C::MT; ++kt) {
+        const int i = nt * C::MT + 2 * kt;
+        const f4& fa = ring.at(i);
+        const f4& fb = ring.at(i + 1);
 #pragma unroll
-        for (int ft = 0; ft < NF; ++ft) h[nt][ft] = EDTTS_MFMA(w[r], xin[kt][ft][r], h[nt][ft]);
-    }
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+          for (int ft = 0; ft < NF; ++ft) h[nt][ft] = EDTTS_MFMA(fa[r], xin[kt][ft][r], h[nt][ft]);
+#pragma unroll
+          for (int ft = 0; ft < NF; ++ft) h[nt + 1][ft] = EDTTS_MFMA(fb[r], xin[kt][ft][r], h[nt + 1][ft]);
+        }
+        ring.template refill_after<N>(i);
+        ring.template refill_after<N>(i + 1);
+      }
+    ring.advance(N);
   }
   {  // (padding waves have returned)
     float* hp = a.h + ((size_t)b * a.Tp + m0 + fq) * C::H + 4 * g;
@@ -1016,7 +1032,7 @@ struct Launcher {
       a.q_out = wsb + ws.q + out_set * qk_set; a.k_out = wsb + ws.k + out_set * qk_set; a.vT_out = wsb + ws.vT + out_set * v_set;
     };
     set_qkv(1, 0);  // the prologue writes set 0
-    a.n1w = blob + lo.layer[0].n1w; a.stream = blob + lo.layer[0].s_qkv; a.layer = 0;
+    a.n1w = blob + lo.layer[0].n1w; a.stream = blob + lo.inp; a.layer = 0;  // stream: inp | qkv(0)
     hipLaunchKernelGGL(k_prologue<C>, dim3(g), dim3(C::THREADS), ring_lds(), st, a);
     LAUNCH_CHECK("k_prologue");
     for (int l = 0; l < lo.L; ++l) {
@@ -1202,7 +1218,7 @@ int edtts_pack_weights(const EdttsDims* dims, const void* const* slots, int n_sl
   TRY(transpose_f(st, G(G_T3_W), blob + lo.t3T, H, H));
   TRY(copy_f(st, G(G_T3_B), blob + lo.t3b, H));
   TRY(copy_f(st, G(G_STEP), blob + lo.step, (size_t)lo.NSTEP * H));
-  TRY(pack_gemm(st, G(G_INP_W), lo.MEL, H, lo.MEL, HT, MT, 0, 0, 0, DH, DHP, blob + lo.inp));
+  TRY(pack_gemm(st, G(G_INP_W), lo.MEL, H, lo.MEL, HT, MT, 0, 0, 4, DH, DHP, blob + lo.inp));  // n-tile pairs, head of the stream
   TRY(copy_f(st, G(G_INP_B), blob + lo.inp_b, H));
   TRY(copy_f(st, G(G_PE), blob + lo.pe, (size_t)lo.MAXPOS * H));
   TRY(copy_f(st, G(G_CPE), blob + lo.cpe, (size_t)lo.MAXCPOS * H));
