@@ -574,6 +574,18 @@ EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, cons
 
       f4 SA[CH][2], SB[CH][2];
       qk(q, 0, KA, qa, qr, SA);  // scores of chunk 0; KB holds chunk 1, VA chunk 0
+      // The reference point starts at chunk 0's row maximum (clamped to the finite -1e30 for fully masked rows): O and the row
+      // sums are still zero, so there is nothing to rescale -- without this the rescale branch runs its whole O *= alpha path
+      // on zeros at the first step of every head.
+#pragma unroll
+      for (int ft = 0; ft < 2; ++ft) {
+        f4 mv = SA[0][ft];
+#pragma unroll
+        for (int t = 1; t < CH; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) mv[r] = fmaxf(mv[r], SA[t][ft][r]);
+        mrun[ft] = fmaxf(mrun[ft], group_max(hmax(mv)));
+      }
       using Yes = std::integral_constant<bool, true>;
       using No = std::integral_constant<bool, false>;
       int c = 0;
