@@ -284,6 +284,27 @@ template <class C> using WStream = FragRing<((C::HT * 2) / C::NF >= 2 && C::HT %
 #ifndef EDTTS_ACLUMP
 #define EDTTS_ACLUMP 1
 #endif
+// acc *= alpha for an MFMA accumulator without exposing VALU arithmetic on it to the compiler.  On the rare rescale path of the
+// online softmax a plain `O *= alpha` makes hipcc hoist 24 v_accvgpr_reads of O into EVERY softmax step (speculatively, above the
+// branch).  The asm keeps O in the AGPR class; s_nops cover the MFMA-write -> read, VALU -> accvgpr_write and write -> MFMA-read
+// hazards, which the hazard recognizer cannot see inside inline asm (the path runs about once per head).
+EDTTS_DEV void scale_acc(f4& o, float alpha) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    float x = o[r], t;
+    asm volatile("s_nop 15\n\tv_accvgpr_read_b32 %1, %0\n\ts_nop 1\n\tv_mul_f32 %1, %1, %2\n\ts_nop 1\n\tv_accvgpr_write_b32 %0, %1\n\ts_nop 3"
+                 : "+a"(x), "=&v"(t)
+                 : "v"(alpha));
+    o[r] = x;
+  }
+}
+
+#ifndef EDTTS_SCALE_ASM
+#define EDTTS_SCALE_ASM 1
+#endif
+#ifndef EDTTS_SERIAL_ATTN
+#define EDTTS_SERIAL_ATTN 1
+#endif
 constexpr int kChunk = 2;  // key tiles (16 keys each) per online-softmax step
 constexpr float kDefer = 32.f;  // octaves a chunk may exceed the softmax reference point before it is moved
 
@@ -457,8 +478,13 @@ EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, cons
   // starts on an exposed load.
   f4 qa_n[2][DFULL > 0 ? DFULL : 1];
   f2 qr_n[2];
+#if EDTTS_SERIAL_ATTN
+  KVFrag<C> KA;
+  VFrag<C> VA;
+#else
   KVFrag<C> KA, KB;
   VFrag<C> VA, VB;
+#endif
   auto prefetch = [&](const Geo& q, int hd, int half) {
 #pragma unroll
     for (int ft = 0; ft < 2; ++ft) {
@@ -467,7 +493,9 @@ EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, cons
       if (DREM) qr_n[ft] = qload.q2(2 * half + ft, hd * DH + 16 * DFULL + 2 * g);
     }
     load_k(q, hd, 0, KA);
+#if !EDTTS_SERIAL_ATTN
     load_k(q, hd, 1, KB);
+#endif
     load_v(q, hd, 0, VA);
     __builtin_amdgcn_sched_barrier(0);
   };
@@ -494,6 +522,76 @@ EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, cons
       for (int dt = 0; dt < DT; ++dt) O[dt][2 * hf] = O[dt][2 * hf + 1] = splat(0.f);
       const int nchunk = q.nchunk;
 
+#if EDTTS_SERIAL_ATTN
+      // Strictly serial step, single S / K / V^T buffers:  K Q^T(c) | softmax(c) | P V(c).  Nothing overlaps an fp32 MFMA on this
+      // chip, so producing the scores of chunk c+1 "under" the softmax of chunk c buys nothing -- but its second
+      // S buffer and the double-buffered K / V^T fragments cost 60 registers and the rotation moves between them.  Each buffer is
+      // reloaded right after the MFMAs that read it were issued and consumed one step later (loop-carried: hipcc cannot sink it).
+      f4 S[CH][2];
+      for (int c = 0; c < nchunk; ++c) {
+        qk(q, c, KA, qa, qr, S);
+        __builtin_amdgcn_sched_barrier(0);
+#ifndef EDTTS_ABLATE_KVLOADS  // timing ablation only
+        load_k(q, hd, c + 1, KA);  // chunk index clamped inside: the last step re-reads its own (valid) tiles
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+        float mxl[2];
+#pragma unroll
+        for (int ft = 0; ft < 2; ++ft) {
+          f4 mv = S[0][ft];
+#pragma unroll
+          for (int t = 1; t < CH; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mv[r] = fmaxf(mv[r], S[t][ft][r]);
+          mxl[ft] = hmax(mv);
+        }
+        // deferred running maximum (see the pipelined variant below); on chunk 0 there is nothing to rescale yet
+        if (__any((mxl[0] > mrun[0] + kDefer) || (mxl[1] > mrun[1] + kDefer))) {
+#pragma unroll
+          for (int ft = 0; ft < 2; ++ft) {
+            const float mnew = fmaxf(mrun[ft], group_max(mxl[ft]));
+            const float alpha = fast_exp2(mrun[ft] - mnew);
+            mrun[ft] = mnew;
+            if (c > 0) {
+              lvec[ft] *= alpha;
+#pragma unroll
+              for (int dt = 0; dt < DT; ++dt) {
+#if EDTTS_SCALE_ASM
+                scale_acc(O[dt][2 * hf + ft], alpha);
+#else
+                O[dt][2 * hf + ft] *= alpha;
+#endif
+              }
+            }
+          }
+        }
+        f4 P[CH][2];
+#pragma unroll
+        for (int ft = 0; ft < 2; ++ft) {
+#pragma unroll
+          for (int t = 0; t < CH; ++t) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) P[t][ft][r] = fast_exp2(S[t][ft][r] - mrun[ft]);
+            lvec[ft] += P[t][ft];
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < CH; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+              O[dt][2 * hf] = EDTTS_MFMA(VA.v[t][dt][r], P[t][0][r], O[dt][2 * hf]);
+              O[dt][2 * hf + 1] = EDTTS_MFMA(VA.v[t][dt][r], P[t][1][r], O[dt][2 * hf + 1]);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+#ifndef EDTTS_ABLATE_KVLOADS
+        load_v(q, hd, c + 1, VA);
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#else
       // One step: finish chunk c (softmax + P V) while the scores of chunk c+1 are produced.
       //   Sc   : scores of chunk c (complete)          Sn : receives the scores of chunk c+1 (its mask is already in it)
       //   Kuse : K fragments of chunk c+1 (loaded one step ago)     Kld : receives the K fragments of chunk c+2
@@ -599,6 +697,7 @@ EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, cons
       } else {                // one chunk left
         step(No{}, c, SA, SB, KB, KA, VA, VB);
       }
+#endif  // EDTTS_SERIAL_ATTN
       // normalise this half's rows
 #pragma unroll
       for (int ft = 0; ft < 2; ++ft) {
