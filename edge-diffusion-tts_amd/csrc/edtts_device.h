@@ -281,9 +281,6 @@ EDTTS_DEV float silu(float g) { return g * __builtin_amdgcn_rcpf(1.0f + __expf(-
 // Ring size: HT fragments at NF = 2, HT/2 at NF = 4 -- the same prefetch distance in MFMAs (4*NF per fragment).
 template <class C> using WStream = FragRing<((C::HT * 2) / C::NF >= 2 && C::HT % ((C::HT * 2) / C::NF) == 0 ? (C::HT * 2) / C::NF : C::HT)>;
 
-#ifndef EDTTS_ACLUMP
-#define EDTTS_ACLUMP 1
-#endif
 // acc *= alpha for an MFMA accumulator without exposing VALU arithmetic on it to the compiler.  On the rare rescale path of the
 // online softmax a plain `O *= alpha` makes hipcc hoist 24 v_accvgpr_reads of O into EVERY softmax step (speculatively, above the
 // branch).  The asm keeps O in the AGPR class; s_nops cover the MFMA-write -> read, VALU -> accvgpr_write and write -> MFMA-read
@@ -299,12 +296,6 @@ EDTTS_DEV void scale_acc(f4& o, float alpha) {
   }
 }
 
-#ifndef EDTTS_SCALE_ASM
-#define EDTTS_SCALE_ASM 1
-#endif
-#ifndef EDTTS_SERIAL_ATTN
-#define EDTTS_SERIAL_ATTN 1
-#endif
 constexpr int kChunk = 2;  // key tiles (16 keys each) per online-softmax step
 constexpr float kDefer = 32.f;  // octaves a chunk may exceed the softmax reference point before it is moved
 
@@ -478,13 +469,8 @@ EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, cons
   // starts on an exposed load.
   f4 qa_n[2][DFULL > 0 ? DFULL : 1];
   f2 qr_n[2];
-#if EDTTS_SERIAL_ATTN
   KVFrag<C> KA;
   VFrag<C> VA;
-#else
-  KVFrag<C> KA, KB;
-  VFrag<C> VA, VB;
-#endif
   auto prefetch = [&](const Geo& q, int hd, int half) {
 #pragma unroll
     for (int ft = 0; ft < 2; ++ft) {
@@ -493,9 +479,6 @@ EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, cons
       if (DREM) qr_n[ft] = qload.q2(2 * half + ft, hd * DH + 16 * DFULL + 2 * g);
     }
     load_k(q, hd, 0, KA);
-#if !EDTTS_SERIAL_ATTN
-    load_k(q, hd, 1, KB);
-#endif
     load_v(q, hd, 0, VA);
     __builtin_amdgcn_sched_barrier(0);
   };
@@ -522,7 +505,6 @@ EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, cons
       for (int dt = 0; dt < DT; ++dt) O[dt][2 * hf] = O[dt][2 * hf + 1] = splat(0.f);
       const int nchunk = q.nchunk;
 
-#if EDTTS_SERIAL_ATTN
       // Strictly serial step, single S / K / V^T buffers:  K Q^T(c) | softmax(c) | P V(c).  Nothing overlaps an fp32 MFMA on this
       // chip, so producing the scores of chunk c+1 "under" the softmax of chunk c buys nothing -- but its second
       // S buffer and the double-buffered K / V^T fragments cost 60 registers and the rotation moves between them.  Each buffer is
@@ -545,7 +527,11 @@ EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, cons
             for (int r = 0; r < 4; ++r) mv[r] = fmaxf(mv[r], S[t][ft][r]);
           mxl[ft] = hmax(mv);
         }
-        // deferred running maximum (see the pipelined variant below); on chunk 0 there is nothing to rescale yet
+        // Online softmax with a DEFERRED running maximum: fp32 accumulators have ~2^127 of headroom, so the reference point
+        // m only has to move when a chunk exceeds it by more than 2^kDefer; until then P = 2^(s - m) <= 2^kDefer and neither O
+        // nor the row sums need rescaling (softmax is invariant to m).  The wave-uniform branch is taken on the first chunk
+        // (m starts at -1e30; nothing to rescale yet) and then only when some row's scores jump by > kDefer octaves; it keeps
+        // the read-modify-write of the O accumulators and the cross-lane max out of the common path.
         if (__any((mxl[0] > mrun[0] + kDefer) || (mxl[1] > mrun[1] + kDefer))) {
 #pragma unroll
           for (int ft = 0; ft < 2; ++ft) {
@@ -556,11 +542,7 @@ EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, cons
               lvec[ft] *= alpha;
 #pragma unroll
               for (int dt = 0; dt < DT; ++dt) {
-#if EDTTS_SCALE_ASM
                 scale_acc(O[dt][2 * hf + ft], alpha);
-#else
-                O[dt][2 * hf + ft] *= alpha;
-#endif
               }
             }
           }
@@ -591,113 +573,6 @@ EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, cons
 #endif
         __builtin_amdgcn_sched_barrier(0);
       }
-#else
-      // One step: finish chunk c (softmax + P V) while the scores of chunk c+1 are produced.
-      //   Sc   : scores of chunk c (complete)          Sn : receives the scores of chunk c+1 (its mask is already in it)
-      //   Kuse : K fragments of chunk c+1 (loaded one step ago)     Kld : receives the K fragments of chunk c+2
-      //   Vuse : V^T fragments of chunk c (loaded one step ago)     Vld : receives the V^T fragments of chunk c+1
-      // Every load is consumed in a LATER step (loop-carried), which is what keeps hipcc from sinking it next to its use:
-      // a V load issued and used within the same step was moved across the rescale branch right in front of the P V MFMAs.
-      // The caller alternates the S / K / V buffers, so nothing is copied between steps.
-      auto step = [&](auto has_next, int c, f4 (&Sc)[CH][2], f4 (&Sn)[CH][2], const KVFrag<C>& Kuse, KVFrag<C>& Kld,
-                      const VFrag<C>& Vuse, VFrag<C>& Vld) {
-#ifndef EDTTS_ABLATE_KVLOADS  // timing ablation only
-        if (decltype(has_next)::value) {
-          load_v(q, hd, c + 1, Vld);
-          load_k(q, hd, c + 2, Kld);
-        }
-#endif
-        __builtin_amdgcn_sched_barrier(0);
-        // scores of the NEXT chunk: independent MFMA work that overlaps this chunk's softmax VALU (same scheduling region)
-        if (decltype(has_next)::value) qk(q, c + 1, Kuse, qa, qr, Sn);
-#if EDTTS_ACLUMP
-        __builtin_amdgcn_sched_barrier(0);  // MFMA run | VALU clump | MFMA run: every switch costs ~8 cycles (mfma_probe3)
-#endif
-#ifdef EDTTS_ABLATE_SOFTMAX  // timing ablation only: P = S (no max, no exp, no rescale); results are wrong by construction
-        f4 P[CH][2];
-#pragma unroll
-        for (int t = 0; t < CH; ++t) { P[t][0] = Sc[t][0]; P[t][1] = Sc[t][1]; lvec[0] += Sc[t][0]; }
-#else
-        // Online softmax with a DEFERRED running maximum: fp32 accumulators have ~2^127 of headroom, so the reference point
-        // m only has to move when a chunk exceeds it by more than 2^kDefer; until then P = 2^(s - m) <= 2^kDefer and neither O
-        // nor the row sums need rescaling (softmax is invariant to m).  The wave-uniform branch is taken on the first chunk
-        // (m starts at -1e30) and then only when some row's scores jump by > kDefer octaves; it removes the per-chunk
-        // read-modify-write of the O accumulators and the cross-lane max from the common path.
-        float mxl[2];
-#pragma unroll
-        for (int ft = 0; ft < 2; ++ft) {
-          f4 mv = Sc[0][ft];
-#pragma unroll
-          for (int t = 1; t < CH; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) mv[r] = fmaxf(mv[r], Sc[t][ft][r]);
-          mxl[ft] = hmax(mv);
-        }
-        if (__any((mxl[0] > mrun[0] + kDefer) || (mxl[1] > mrun[1] + kDefer))) {
-#pragma unroll
-          for (int ft = 0; ft < 2; ++ft) {
-            const float mnew = fmaxf(mrun[ft], group_max(mxl[ft]));  // identical on the 4 lanes of a row
-            const float alpha = fast_exp2(mrun[ft] - mnew);           // mrun starts finite (-1e30): never NaN
-            mrun[ft] = mnew;
-            lvec[ft] *= alpha;
-#pragma unroll
-            for (int dt = 0; dt < DT; ++dt) O[dt][2 * hf + ft] *= alpha;
-          }
-        }
-        f4 P[CH][2];
-#pragma unroll
-        for (int ft = 0; ft < 2; ++ft) {
-#pragma unroll
-          for (int t = 0; t < CH; ++t) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) P[t][ft][r] = fast_exp2(Sc[t][ft][r] - mrun[ft]);
-            lvec[ft] += P[t][ft];
-          }
-        }
-#endif
-#if EDTTS_ACLUMP
-        __builtin_amdgcn_sched_barrier(0);
-#endif
-        // O^T += V^T P^T : DT x 2 independent accumulators, r outermost
-#pragma unroll
-        for (int t = 0; t < CH; ++t)
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int dt = 0; dt < DT; ++dt) {
-              O[dt][2 * hf] = EDTTS_MFMA(Vuse.v[t][dt][r], P[t][0][r], O[dt][2 * hf]);
-              O[dt][2 * hf + 1] = EDTTS_MFMA(Vuse.v[t][dt][r], P[t][1][r], O[dt][2 * hf + 1]);
-            }
-      };
-
-      f4 SA[CH][2], SB[CH][2];
-      qk(q, 0, KA, qa, qr, SA);  // scores of chunk 0; KB holds chunk 1, VA chunk 0
-      // The reference point starts at chunk 0's row maximum (clamped to the finite -1e30 for fully masked rows): O and the row
-      // sums are still zero, so there is nothing to rescale -- without this the rescale branch runs its whole O *= alpha path
-      // on zeros at the first step of every head.
-#pragma unroll
-      for (int ft = 0; ft < 2; ++ft) {
-        f4 mv = SA[0][ft];
-#pragma unroll
-        for (int t = 1; t < CH; ++t)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) mv[r] = fmaxf(mv[r], SA[t][ft][r]);
-        mrun[ft] = fmaxf(mrun[ft], group_max(hmax(mv)));
-      }
-      using Yes = std::integral_constant<bool, true>;
-      using No = std::integral_constant<bool, false>;
-      int c = 0;
-      for (; c + 2 < nchunk; c += 2) {
-        step(Yes{}, c, SA, SB, KB, KA, VA, VB);      // finishes chunk c; scores of c+1 -> SB (from KB); loads K(c+2) -> KA, V(c+1) -> VB
-        step(Yes{}, c + 1, SB, SA, KA, KB, VB, VA);  // finishes chunk c+1; scores of c+2 -> SA (from KA); loads K(c+3) -> KB, V(c+2) -> VA
-      }
-      if (nchunk - c == 2) {  // two chunks left: scores of c are in SA, V(c) in VA
-        step(Yes{}, c, SA, SB, KB, KA, VA, VB);
-        step(No{}, c + 1, SB, SA, KA, KB, VB, VA);
-      } else {                // one chunk left
-        step(No{}, c, SA, SB, KB, KA, VA, VB);
-      }
-#endif  // EDTTS_SERIAL_ATTN
       // normalise this half's rows
 #pragma unroll
       for (int ft = 0; ft < 2; ++ft) {
