@@ -59,6 +59,14 @@ EDTTS_DEV f4 splat(float v) { return f4{v, v, v, v}; }
 EDTTS_DEV f4 ldg4(const float* p) { return *reinterpret_cast<const f4*>(p); }
 EDTTS_DEV f2 ldg2(const float* p) { return *reinterpret_cast<const f2*>(p); }
 EDTTS_DEV void stg4(float* p, f4 v) { *reinterpret_cast<f4*>(p) = v; }
+// Loads from a wave-uniform base plus a per-lane 32-bit byte offset: the uniform part is SALU arithmetic, the lane part never
+// changes, and hipcc keeps one hoisted per-lane pointer per stream instead of rebuilding 64-bit addresses for every load.
+EDTTS_DEV f4 ldg4_sbase(const float* base, unsigned byte_off) {
+  return *reinterpret_cast<const f4*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+EDTTS_DEV f2 ldg2_sbase(const float* base, unsigned byte_off) {
+  return *reinterpret_cast<const f2*>(reinterpret_cast<const char*>(base) + byte_off);
+}
 
 // Correctly rounded fp32 sqrt / divide via fp64 (53 >= 2*24+2 bits, so rounding the fp64 result to fp32 is the
 // IEEE fp32 result) -- the device's fp32 sqrt is not guaranteed correctly rounded, the reference's CPU one is.
@@ -371,17 +379,21 @@ EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, cons
     return q;
   };
 
-  // loads of one chunk's K / V^T fragments (tile index clamped: tiles past kt_hi are fully masked by klim)
+  // loads of one chunk's K / V^T fragments (tile index clamped: tiles past kt_hi are fully masked by klim).  Every address is
+  // a wave-uniform base (SALU arithmetic on the tile / head indices) plus a per-lane 32-bit byte offset that never changes:
+  // 1.5 % faster on the layer kernel than per-load 64-bit address arithmetic on the lanes.
+  const unsigned koff = (unsigned)(fq * H + 4 * g) * 4u, koff_rem = (unsigned)(fq * H + 2 * g) * 4u;
+  const unsigned voff = (unsigned)(fq * ldv + 4 * g) * 4u, voff_rem = (unsigned)(vrow_rem * ldv + 4 * g) * 4u;
   auto load_k = [&](const Geo& q, int hd, int c, KVFrag<C>& f) {
     c = c < q.nchunk ? c : q.nchunk - 1;
 #pragma unroll
     for (int t = 0; t < CH; ++t) {
       int kt = q.kt_lo + c * CH + t;
       kt = kt < q.kt_hi ? kt : q.kt_hi - 1;
-      const float* kp = Kb + (size_t)((kt << 4) + fq) * H + hd * DH;
+      const float* ku = Kb + (size_t)(kt << 4) * H + hd * DH;  // uniform
 #pragma unroll
-      for (int a = 0; a < DFULL; ++a) f.ka[t][a] = ldg4(kp + 16 * a + 4 * g);
-      if (DREM) f.kr[t] = ldg2(kp + 16 * DFULL + 2 * g);
+      for (int a = 0; a < DFULL; ++a) f.ka[t][a] = ldg4_sbase(ku + 16 * a, koff);
+      if (DREM) f.kr[t] = ldg2_sbase(ku + 16 * DFULL, koff_rem);
     }
   };
   auto load_v = [&](const Geo& q, int hd, int c, VFrag<C>& f) {
@@ -391,7 +403,10 @@ EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, cons
       int kt = q.kt_lo + c * CH + t;
       kt = kt < q.kt_hi ? kt : q.kt_hi - 1;
 #pragma unroll
-      for (int dt = 0; dt < DT; ++dt) f.v[t][dt] = ldg4(VTb + (size_t)(hd * DH + 16 * dt + ((DREM && dt == DT - 1) ? vrow_rem : fq)) * ldv + (kt << 4) + 4 * g);
+      for (int dt = 0; dt < DT; ++dt) {
+        const float* vu = VTb + (size_t)(hd * DH + 16 * dt) * ldv + (kt << 4);  // uniform
+        f.v[t][dt] = ldg4_sbase(vu, (DREM && dt == DT - 1) ? voff_rem : voff);
+      }
     }
   };
   // Mask of chunk c as the INITIAL accumulator of its K Q^T product: 0 where the key is visible, -inf elsewhere
