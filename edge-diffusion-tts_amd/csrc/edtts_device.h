@@ -421,7 +421,7 @@ EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, cons
     if (SELF && window >= 0) full = full && (k1 - q.m0 <= window) && (k0 - (q.m0 + 31) >= -window);
     return full;
   };
-  auto mask_init = [&](const Geo& q, int c, f4 (&S)[CH][2]) {
+  auto mask_init = [&](const Geo& q, int c, f4 (&S)[CH][2], const float (&vis)[2]) {  // vis: value of a VISIBLE position
     c = c < q.nchunk ? c : q.nchunk - 1;
     const int k0 = (q.kt_lo + c * CH) << 4;
 #pragma unroll
@@ -432,21 +432,27 @@ EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, cons
 #pragma unroll
       for (int t = 0; t < CH; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) S[t][ft][r] = (unsigned)(d0 + bias + 16 * t + r) <= sp ? 0.f : NEG_INF;
+        for (int r = 0; r < 4; ++r) S[t][ft][r] = (unsigned)(d0 + bias + 16 * t + r) <= sp ? vis[ft] : NEG_INF;
     }
   };
   // S^T chunk = mask + K Q^T for both query tiles, accumulators interleaved (2*CH independent chains)
-  auto qk = [&](const Geo& q, int c, const KVFrag<C>& f, const f4 (&qa)[2][DFULL > 0 ? DFULL : 1], const f2 (&qr)[2],
-                f4 (&S)[CH][2]) {
+  // With FOLD the accumulators start at -m (the softmax reference point of the row) instead of 0, so the scores come out as
+  // s - m and exp2 applies to them directly: m only changes on the rare rescale path, and folding it into the accumulator input
+  // removes a v_sub per score from every step.  nm[ft] = -m as a scalar (edge chunks: the mask select picks it instead of 0),
+  // NM[ft] = the same value as a whole accumulator tile (interior chunks).
+  auto qk = [&](auto fold_tag, const Geo& q, int c, const KVFrag<C>& f, const f4 (&qa)[2][DFULL > 0 ? DFULL : 1],
+                const f2 (&qr)[2], f4 (&S)[CH][2], const f4 (&NM)[2], const float (&nm)[2]) {
     static_assert(DFULL >= 1, "head_dim >= 16 expected");
+    constexpr bool FOLD = decltype(fold_tag)::value;
     if (chunk_is_interior(q, c)) {
 #pragma unroll
       for (int t = 0; t < CH; ++t) {
-        S[t][0] = EDTTS_MFMA(f.ka[t][0][0], qa[0][0][0], splat(0.f));
-        S[t][1] = EDTTS_MFMA(f.ka[t][0][0], qa[1][0][0], splat(0.f));
+        S[t][0] = FOLD ? EDTTS_MFMA(f.ka[t][0][0], qa[0][0][0], NM[0]) : EDTTS_MFMA(f.ka[t][0][0], qa[0][0][0], splat(0.f));
+        S[t][1] = FOLD ? EDTTS_MFMA(f.ka[t][0][0], qa[1][0][0], NM[1]) : EDTTS_MFMA(f.ka[t][0][0], qa[1][0][0], splat(0.f));
       }
     } else {
-      mask_init(q, c, S);
+      const float zero[2] = {0.f, 0.f};
+      mask_init(q, c, S, FOLD ? nm : zero);
 #pragma unroll
       for (int t = 0; t < CH; ++t) {
         S[t][0] = EDTTS_MFMA(f.ka[t][0][0], qa[0][0][0], S[t][0]);
@@ -514,7 +520,6 @@ EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, cons
         for (int a = 0; a < DFULL; ++a) qa[ft][a] = qa_n[ft][a] * c2;
         if (DREM) qr[ft] = qr_n[ft] * c2;
       }
-      float mrun[2] = {-1e30f, -1e30f};
       f4 lvec[2] = {splat(0.f), splat(0.f)};  // per-lane partial row sums (reduced over r and the lane groups at the end)
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) O[dt][2 * hf] = O[dt][2 * hf + 1] = splat(0.f);
@@ -524,54 +529,87 @@ EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, cons
       // chip, so producing the scores of chunk c+1 "under" the softmax of chunk c buys nothing -- but its second
       // S buffer and the double-buffered K / V^T fragments cost 60 registers and the rotation moves between them.  Each buffer is
       // reloaded right after the MFMAs that read it were issued and consumed one step later (loop-carried: hipcc cannot sink it).
+      //
+      // Online softmax with a DEFERRED running maximum: fp32 accumulators have ~2^127 of headroom, so the reference point m only
+      // has to move when a chunk exceeds it by more than 2^kDefer; until then P = 2^(s - m) <= 2^kDefer and neither O nor the
+      // row sums need rescaling (softmax is invariant to m).  Chunk 0 sets m to its row maximum; from chunk 1 on the scores come
+      // out of the MFMAs as s - m (see qk) and the wave-uniform rescale branch is taken only when some row jumps by more than
+      // kDefer octaves -- the read-modify-write of O, the cross-lane max and the subtraction of m stay out of the common path.
       f4 S[CH][2];
-      for (int c = 0; c < nchunk; ++c) {
-        qk(q, c, KA, qa, qr, S);
+      f4 NM[2] = {splat(0.f), splat(0.f)};
+      float nm[2] = {0.f, 0.f};
+      using Yes = std::integral_constant<bool, true>;
+      using No = std::integral_constant<bool, false>;
+      auto step = [&](auto fold_tag, int c) {
+        constexpr bool FOLD = decltype(fold_tag)::value;
+        qk(fold_tag, q, c, KA, qa, qr, S, NM, nm);
         __builtin_amdgcn_sched_barrier(0);
 #ifndef EDTTS_ABLATE_KVLOADS  // timing ablation only
         load_k(q, hd, c + 1, KA);  // chunk index clamped inside: the last step re-reads its own (valid) tiles
 #endif
         __builtin_amdgcn_sched_barrier(0);
+        // one VGPR copy of the scores serves the maximum, the rare rescale and exp2 (the pin keeps hipcc from re-reading the
+        // accumulators after the branch)
+        f4 sv[CH][2];
+#pragma unroll
+        for (int t = 0; t < CH; ++t)
+#pragma unroll
+          for (int ft = 0; ft < 2; ++ft) {
+            sv[t][ft] = S[t][ft];
+            asm volatile("" : "+v"(sv[t][ft]));
+          }
         float mxl[2];
 #pragma unroll
         for (int ft = 0; ft < 2; ++ft) {
-          f4 mv = S[0][ft];
+          f4 mv = sv[0][ft];
 #pragma unroll
           for (int t = 1; t < CH; ++t)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) mv[r] = fmaxf(mv[r], S[t][ft][r]);
+            for (int r = 0; r < 4; ++r) mv[r] = fmaxf(mv[r], sv[t][ft][r]);
           mxl[ft] = hmax(mv);
         }
-        // Online softmax with a DEFERRED running maximum: fp32 accumulators have ~2^127 of headroom, so the reference point
-        // m only has to move when a chunk exceeds it by more than 2^kDefer; until then P = 2^(s - m) <= 2^kDefer and neither O
-        // nor the row sums need rescaling (softmax is invariant to m).  The wave-uniform branch is taken on the first chunk
-        // (m starts at -1e30; nothing to rescale yet) and then only when some row's scores jump by > kDefer octaves; it keeps
-        // the read-modify-write of the O accumulators and the cross-lane max out of the common path.
-        if (__any((mxl[0] > mrun[0] + kDefer) || (mxl[1] > mrun[1] + kDefer))) {
+        f4 P[CH][2];
+        if (!FOLD) {
+          // first chunk: the reference point is this chunk's row maximum (0 for a row without any visible key: stays finite)
 #pragma unroll
           for (int ft = 0; ft < 2; ++ft) {
-            const float mnew = fmaxf(mrun[ft], group_max(mxl[ft]));
-            const float alpha = fast_exp2(mrun[ft] - mnew);
-            mrun[ft] = mnew;
-            if (c > 0) {
+            const float gm = group_max(mxl[ft]);  // identical on the 4 lanes of a row
+            const float m = gm > -1e30f ? gm : 0.f;
+            nm[ft] = -m;
+            NM[ft] = splat(-m);
+            asm volatile("" : "+a"(NM[ft]));  // the -m tile lives in AGPRs: it is an accumulator input and nothing else
+#pragma unroll
+            for (int t = 0; t < CH; ++t)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) P[t][ft][r] = fast_exp2(sv[t][ft][r] - m);
+          }
+        } else {
+          if (__any((mxl[0] > kDefer) || (mxl[1] > kDefer))) {
+#pragma unroll
+            for (int ft = 0; ft < 2; ++ft) {
+              const float delta = fmaxf(0.f, group_max(mxl[ft]));  // rows that did not jump keep their reference
+              const float alpha = fast_exp2(-delta);
+              nm[ft] -= delta;
+              NM[ft] = splat(nm[ft]);
+              asm volatile("" : "+a"(NM[ft]));
               lvec[ft] *= alpha;
 #pragma unroll
-              for (int dt = 0; dt < DT; ++dt) {
-                scale_acc(O[dt][2 * hf + ft], alpha);
-              }
+              for (int t = 0; t < CH; ++t) sv[t][ft] -= delta;
+#pragma unroll
+              for (int dt = 0; dt < DT; ++dt) scale_acc(O[dt][2 * hf + ft], alpha);
             }
           }
+#pragma unroll
+          for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+            for (int t = 0; t < CH; ++t)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) P[t][ft][r] = fast_exp2(sv[t][ft][r]);
         }
-        f4 P[CH][2];
 #pragma unroll
-        for (int ft = 0; ft < 2; ++ft) {
+        for (int ft = 0; ft < 2; ++ft)
 #pragma unroll
-          for (int t = 0; t < CH; ++t) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) P[t][ft][r] = fast_exp2(S[t][ft][r] - mrun[ft]);
-            lvec[ft] += P[t][ft];
-          }
-        }
+          for (int t = 0; t < CH; ++t) lvec[ft] += P[t][ft];
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int t = 0; t < CH; ++t)
@@ -587,7 +625,9 @@ EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, cons
         load_v(q, hd, c + 1, VA);
 #endif
         __builtin_amdgcn_sched_barrier(0);
-      }
+      };
+      step(No{}, 0);
+      for (int c = 1; c < nchunk; ++c) step(Yes{}, c);
       // normalise this half's rows
 #pragma unroll
       for (int ft = 0; ft < 2; ++ft) {
