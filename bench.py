@@ -82,7 +82,7 @@ def main():
     torch.cuda.set_device(dev)
 
     from edge_diffusion_tts_amd import CFG, DiffusionSchedule, EdgeDiffusionDecoder, EdgeInference, native, synth_state_dict
-    from edge_diffusion_tts_amd.parallel import gather_batch
+    from edge_diffusion_tts_amd.parallel import gather_batch, generate_overlapped
 
     cfg = CFG(device="cuda")
     dec = EdgeDiffusionDecoder(cfg)
@@ -99,7 +99,13 @@ def main():
     x_T = torch.randn(B, T, cfg.n_mels, generator=torch.Generator().manual_seed(123 + rank)).to(dev)
     stream = torch.cuda.current_stream(dev)
 
+    # EDTTS_BENCH_MICRO=M (>1, opt-in): run the local batch in M slices and overlap each slice's all-gather with the next
+    # slice's compute (parallel.generate_overlapped).  Default 1: one all-gather after the whole local batch.
+    micro = int(os.environ.get("EDTTS_BENCH_MICRO", "1"))
+
     def step():
+        if world > 1 and micro > 1:
+            return generate_overlapped(lambda s_, n_, x_: infer.generate_mel(s_, n_, x_T=x_), sem, x_T, 4, world * B, micro)
         mel = infer.generate_mel(sem, 4, x_T=x_T)
         if world > 1:
             mel = gather_batch(mel, world * B)  # the one collective of the path: final mel batch, RCCL over xGMI
@@ -138,7 +144,8 @@ def main():
         "config": {"workload": f"generate_mel 4-step DDIM, CFG() decoder hidden=160 L=4 heads=4 n_mels=80 window=64, "
                                f"B={B}/GPU T={T} S={S}, synthetic weights + tokens + noise",
                    "batch_per_gpu": B, "frames": T, "ddim_steps": 4,
-                   "parallelism": f"batch-sharded x{world}, all-gather of the final mel batch" if world > 1 else "single GPU"},
+                   "parallelism": (f"batch-sharded x{world}, all-gather of the final mel batch" + (f" overlapped with compute in {micro} slices" if micro > 1 else ""))
+                   if world > 1 else "single GPU"},
         "mels_per_s": world * B / (dt / args.steps),
     }
     if rehearsal:

@@ -49,6 +49,35 @@ def gather_batch(local: torch.Tensor, total: int, group=None) -> torch.Tensor:
     return torch.cat([buf[r * mx: r * mx + sizes[r]] for r in range(world)], dim=0)
 
 
+def generate_overlapped(local_generate: Callable, sem_local: torch.Tensor, x_local: torch.Tensor, num_steps: int, total: int,
+                        micro_batches: int, group=None) -> torch.Tensor:
+    """Local sampler in `micro_batches` slices, the all-gather of slice i running while slice i+1 computes.
+
+    Every rank must hold an equal shard whose size is divisible by `micro_batches`.  Slice i of rank r lands at rows
+    [r*Bl + i*Bm, r*Bl + (i+1)*Bm) of the result, i.e. the output is identical to the un-overlapped gather.  With the nccl
+    backend each all_gather is asynchronous on the process group's stream (it waits for the slice that was just enqueued and
+    overlaps the next one); the results are joined before returning.  OPT-IN: the one-shot gather stays the default until the
+    overlap has been measured on a multi-GPU node."""
+    world = dist.get_world_size(group)
+    Bl = sem_local.shape[0]
+    if Bl * world != total or micro_batches < 1 or Bl % micro_batches:
+        raise ValueError(f"equal shards divisible by micro_batches required: total={total} world={world} local={Bl} micro_batches={micro_batches}")
+    Bm = Bl // micro_batches
+    staged = sem_local.is_cuda and dist.get_backend(group) == "gloo"  # rehearsal: gloo moves host memory
+    out, works, keep = None, [], []
+    for i in range(micro_batches):
+        mel = local_generate(sem_local[i * Bm:(i + 1) * Bm].contiguous(), num_steps, x_local[i * Bm:(i + 1) * Bm].contiguous())
+        if out is None:
+            out = torch.empty((total,) + tuple(mel.shape[1:]), dtype=mel.dtype, device="cpu" if staged else mel.device)
+        src = mel.cpu() if staged else mel.contiguous()
+        dst = [out[r * Bl + i * Bm: r * Bl + (i + 1) * Bm] for r in range(world)]
+        works.append(dist.all_gather(dst, src, group=group, async_op=True))
+        keep.append(src)
+    for w in works:
+        w.wait()
+    return out.to(sem_local.device) if staged else out
+
+
 class ShardedEdgeInference:
     """generate_mel over a process group: every rank passes the SAME global sem_idx (and optionally the same global
     x_T); each computes its contiguous block with `local_generate` and receives the full [B, 2S, n_mels] result.
@@ -57,11 +86,12 @@ class ShardedEdgeInference:
     wrapped object.  The start noise is drawn for the GLOBAL batch from `seed` and sliced, so the result does not depend
     on the number of ranks (bitwise)."""
 
-    def __init__(self, infer=None, local_generate: Optional[Callable] = None, group=None):
+    def __init__(self, infer=None, local_generate: Optional[Callable] = None, group=None, micro_batches: int = 1):
         if infer is None and local_generate is None:
             raise ValueError("need an EdgeInference or a local_generate callable")
         self.infer = infer
         self.group = group
+        self.micro_batches = int(micro_batches)  # > 1: overlap the all-gather with compute (generate_overlapped; opt-in)
         self._local = local_generate or (lambda sem, n, x: infer.generate_mel(sem, n, x_T=x))
 
     def generate_mel(self, sem_idx: torch.Tensor, num_steps: int = 4, temperature: float = 1.0, *, x_T: Optional[torch.Tensor] = None,
@@ -73,5 +103,7 @@ class ShardedEdgeInference:
             m = n_mels if n_mels is not None else self.infer.cfg.n_mels
             g = torch.Generator(device=sem_idx.device).manual_seed(seed)
             x_T = torch.randn(B, 2 * S, m, device=sem_idx.device, generator=g) * temperature
+        if self.micro_batches > 1 and B % world == 0 and (B // world) % self.micro_batches == 0:
+            return generate_overlapped(self._local, sem_idx[lo:hi], x_T[lo:hi], num_steps, B, self.micro_batches, self.group)
         local = self._local(sem_idx[lo:hi].contiguous(), num_steps, x_T[lo:hi].contiguous())
         return gather_batch(local, B, self.group)

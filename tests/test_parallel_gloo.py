@@ -45,6 +45,10 @@ def _worker(rank, world, port, total, q):
         gg = torch.Generator().manual_seed(11)
         ref2 = _fake_local_generate(sem, 4, torch.randn(total, 12, 5, generator=gg))
         ok = ok and torch.equal(out2, ref2)
+        # opt-in overlap of the all-gather with compute: identical result whenever the shards split evenly (else it falls back)
+        for micro in (2, 4):
+            sh_mb = ShardedEdgeInference(local_generate=_fake_local_generate, micro_batches=micro)
+            ok = ok and torch.equal(sh_mb.generate_mel(sem, 4, x_T=x_T), ref)
         # raw gather with ragged shards
         lo, hi = shard_bounds(total, world, rank)
         ok = ok and torch.equal(gather_batch(ref[lo:hi].clone(), total), ref)
@@ -59,7 +63,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("world,total", [(2, 8), (2, 7), (3, 10)])
+@pytest.mark.parametrize("world,total", [(2, 8), (2, 7), (3, 10), (2, 16)])
 def test_sharded_generate_gloo(world, total):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
