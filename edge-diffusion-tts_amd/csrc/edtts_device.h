@@ -548,8 +548,8 @@ EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, cons
         load_k(q, hd, c + 1, KA);  // chunk index clamped inside: the last step re-reads its own (valid) tiles
 #endif
         __builtin_amdgcn_sched_barrier(0);
-        // one VGPR copy of the scores serves the maximum, the rare rescale and exp2 (the pin keeps hipcc from re-reading the
-        // accumulators after the branch)
+        // one VGPR copy of the scores serves exp2 and the rare rescale (the pin keeps hipcc from re-reading the accumulators
+        // after the branch)
         f4 sv[CH][2];
 #pragma unroll
         for (int t = 0; t < CH; ++t)
@@ -558,58 +558,61 @@ EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, cons
             sv[t][ft] = S[t][ft];
             asm volatile("" : "+v"(sv[t][ft]));
           }
-        float mxl[2];
-#pragma unroll
-        for (int ft = 0; ft < 2; ++ft) {
+        auto lane_max = [&](int ft) {  // maximum over this lane's 4*CH scores of query tile ft
           f4 mv = sv[0][ft];
 #pragma unroll
           for (int t = 1; t < CH; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) mv[r] = fmaxf(mv[r], sv[t][ft][r]);
-          mxl[ft] = hmax(mv);
-        }
-        f4 P[CH][2];
+          return hmax(mv);
+        };
+        f4 P[CH][2], ps[2];  // ps: this chunk's partial row sums (per lane)
+        auto exp_and_sum = [&](int ft, float m) {
+#pragma unroll
+          for (int t = 0; t < CH; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) P[t][ft][r] = fast_exp2(sv[t][ft][r] - m);
+          ps[ft] = P[0][ft];
+#pragma unroll
+          for (int t = 1; t < CH; ++t) ps[ft] += P[t][ft];
+        };
         if (!FOLD) {
           // first chunk: the reference point is this chunk's row maximum (0 for a row without any visible key: stays finite)
 #pragma unroll
           for (int ft = 0; ft < 2; ++ft) {
-            const float gm = group_max(mxl[ft]);  // identical on the 4 lanes of a row
+            const float gm = group_max(lane_max(ft));  // identical on the 4 lanes of a row
             const float m = gm > -1e30f ? gm : 0.f;
             nm[ft] = -m;
             NM[ft] = splat(-m);
             asm volatile("" : "+a"(NM[ft]));  // the -m tile lives in AGPRs: it is an accumulator input and nothing else
-#pragma unroll
-            for (int t = 0; t < CH; ++t)
-#pragma unroll
-              for (int r = 0; r < 4; ++r) P[t][ft][r] = fast_exp2(sv[t][ft][r] - m);
+            exp_and_sum(ft, m);
           }
         } else {
-          if (__any((mxl[0] > kDefer) || (mxl[1] > kDefer))) {
+          // The scores are already relative to the reference point.  Whether it has to move is read off the partial row sums,
+          // which are needed anyway: sum(P) > 2^kDefer (or not finite) <=> some score may exceed m by more than kDefer octaves
+          // (no false negatives: sum >= max; a false positive only moves the reference early).  The per-lane maximum, the
+          // cross-lane max and the read-modify-write of O then stay out of the common path entirely.
+          exp_and_sum(0, 0.f);
+          exp_and_sum(1, 0.f);
+          const float lim = 4294967296.f;  // 2^kDefer
+          static_assert(kDefer == 32.f, "lim above is 2^kDefer");
+          if (__any(!(hsum(ps[0]) <= lim) || !(hsum(ps[1]) <= lim))) {
 #pragma unroll
             for (int ft = 0; ft < 2; ++ft) {
-              const float delta = fmaxf(0.f, group_max(mxl[ft]));  // rows that did not jump keep their reference
+              const float delta = fmaxf(0.f, group_max(lane_max(ft)));  // rows that did not jump keep their reference
               const float alpha = fast_exp2(-delta);
               nm[ft] -= delta;
               NM[ft] = splat(nm[ft]);
               asm volatile("" : "+a"(NM[ft]));
               lvec[ft] *= alpha;
 #pragma unroll
-              for (int t = 0; t < CH; ++t) sv[t][ft] -= delta;
-#pragma unroll
               for (int dt = 0; dt < DT; ++dt) scale_acc(O[dt][2 * hf + ft], alpha);
+              exp_and_sum(ft, delta);
             }
           }
-#pragma unroll
-          for (int ft = 0; ft < 2; ++ft)
-#pragma unroll
-            for (int t = 0; t < CH; ++t)
-#pragma unroll
-              for (int r = 0; r < 4; ++r) P[t][ft][r] = fast_exp2(sv[t][ft][r]);
         }
-#pragma unroll
-        for (int ft = 0; ft < 2; ++ft)
-#pragma unroll
-          for (int t = 0; t < CH; ++t) lvec[ft] += P[t][ft];
+        lvec[0] += ps[0];
+        lvec[1] += ps[1];
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int t = 0; t < CH; ++t)
