@@ -348,6 +348,7 @@ EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, cons
   // per-half geometry (a half = 32 query frames starting at m0 = m0w + 32*half)
   struct Geo {
     int m0, kt_lo, kt_hi, nchunk, klim;
+    int cdiag;  // chunk that holds the keys of this half's own frames (self-attention; 0 otherwise)
     int lo_d[2], span[2];  // per-lane band limits on d = key - query: valid <=> (unsigned)(d - lo_d) <= span
   };
   auto make_geo = [&](int half) {
@@ -355,7 +356,7 @@ EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, cons
     q.m0 = m0w + 32 * half;
     if (SELF && window >= 0) {
       const int lo = q.m0 - window;
-      q.kt_lo = (lo > 0 ? lo : 0) >> 4;
+      q.kt_lo = ((lo > 0 ? lo : 0) >> 4) & ~(CH - 1);  // chunk grid aligned to the 32-frame tiles (see cdiag)
       const int hi = q.m0 + 31 + window;  // last key any query of this half may see
       const int last = (hi < nkeys - 1 ? hi : nkeys - 1);
       q.kt_hi = (last >> 4) + 1;
@@ -364,6 +365,12 @@ EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, cons
       q.kt_hi = (nkeys + 15) >> 4;
     }
     q.nchunk = (q.kt_hi - q.kt_lo + CH - 1) / CH;
+    // The softmax is order-independent, and every valid query row can see its own key: starting with the chunk that holds the
+    // diagonal guarantees that the (peeled) first step finds a visible key in every such row and can set its reference point.
+    // (With the band start not on a chunk boundary -- windows that are not multiples of 16 -- chunk 0 is fully masked for some
+    // rows that do see later keys; a reference left at 0 there underflows every exp2 when all scores are far below zero.)
+    q.cdiag = SELF ? ((q.m0 >> 4) - q.kt_lo) / CH : 0;
+    if (q.cdiag >= q.nchunk) q.cdiag = q.nchunk - 1;  // half entirely past the end of the utterance
     q.klim = (q.kt_hi << 4) < nkeys ? (q.kt_hi << 4) : nkeys;  // keys >= klim are never valid
 #pragma unroll
     for (int ft = 0; ft < 2; ++ft) {
@@ -499,8 +506,8 @@ EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, cons
       for (int a = 0; a < DFULL; ++a) qa_n[ft][a] = qload.q4(2 * half + ft, hd * DH + 16 * a + 4 * g);
       if (DREM) qr_n[ft] = qload.q2(2 * half + ft, hd * DH + 16 * DFULL + 2 * g);
     }
-    load_k(q, hd, 0, KA);
-    load_v(q, hd, 0, VA);
+    load_k(q, hd, q.cdiag, KA);  // the first step processes the diagonal chunk
+    load_v(q, hd, q.cdiag, VA);
     __builtin_amdgcn_sched_barrier(0);
   };
   prefetch(geo[0], 0, 0);
@@ -540,12 +547,12 @@ EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, cons
       float nm[2] = {0.f, 0.f};
       using Yes = std::integral_constant<bool, true>;
       using No = std::integral_constant<bool, false>;
-      auto step = [&](auto fold_tag, int c) {
+      auto step = [&](auto fold_tag, int c, int cnext) {  // c: this step's chunk, cnext: the next step's (prefetch)
         constexpr bool FOLD = decltype(fold_tag)::value;
         qk(fold_tag, q, c, KA, qa, qr, S, NM, nm);
         __builtin_amdgcn_sched_barrier(0);
 #ifndef EDTTS_ABLATE_KVLOADS  // timing ablation only
-        load_k(q, hd, c + 1, KA);  // chunk index clamped inside: the last step re-reads its own (valid) tiles
+        load_k(q, hd, cnext, KA);  // (the last step re-reads its own tiles)
 #endif
         __builtin_amdgcn_sched_barrier(0);
         // one VGPR copy of the scores serves exp2 and the rare rescale (the pin keeps hipcc from re-reading the accumulators
@@ -625,12 +632,15 @@ EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, cons
             }
         __builtin_amdgcn_sched_barrier(0);
 #ifndef EDTTS_ABLATE_KVLOADS
-        load_v(q, hd, c + 1, VA);
+        load_v(q, hd, cnext, VA);
 #endif
         __builtin_amdgcn_sched_barrier(0);
       };
-      step(No{}, 0);
-      for (int c = 1; c < nchunk; ++c) step(Yes{}, c);
+      // step s = 0: the diagonal chunk; steps 1 .. nchunk-1: the other chunks in ascending order
+      const int cd = q.cdiag;
+      auto chunk_of = [&](int st) { return st >= nchunk ? nchunk - 1 : (st == 0 ? cd : (st <= cd ? st - 1 : st)); };
+      step(No{}, cd, chunk_of(1));
+      for (int st = 1; st < nchunk; ++st) step(Yes{}, chunk_of(st), chunk_of(st + 1));
       // normalise this half's rows
 #pragma unroll
       for (int ft = 0; ft < 2; ++ft) {

@@ -293,6 +293,37 @@ def test_forward_large_score_range():
     assert ours < max(5e-4, 20 * theirs)
 
 
+@pytest.mark.parametrize("window", [4, 9, 37])
+def test_small_window_all_scores_far_below_zero(window):
+    """Rows whose FIRST key chunk is fully masked (the band does not start on a 32-key chunk boundary) must take their softmax
+    reference from the first chunk that has a visible key -- also when ALL their scores are hundreds of octaves below zero,
+    where a reference left at 0 would underflow every exp2 and normalise the row to 0.  k = -alpha * q with a nearly constant
+    input makes every score q_i . k_j = -alpha |q|^2 hugely negative."""
+    cfg = CFG(device=DEV, attn_window_size=window)
+    sd = synth_state_dict(cfg, 3)
+    H = cfg.hidden
+    for l in range(cfg.layers):
+        w = sd[f"layers.{l}.attn.qkv.weight"]
+        w[H:2 * H] = -6.0 * w[:H]  # k rows = -6 * q rows
+        w[:H] *= 6.0
+    dec = EdgeDiffusionDecoder(cfg)
+    dec.load_state_dict(sd)
+    dec = dec.to(DEV).eval()
+    gen = torch.Generator().manual_seed(6)
+    B, T, S = 2, 160, 80
+    x = torch.randn(B, 1, 80, generator=gen).expand(B, T, 80) * 1.5 + 0.01 * torch.randn(B, T, 80, generator=gen)
+    x = x.contiguous()
+    sem = torch.randint(0, 512, (B, S), generator=gen)
+    t, si = torch.tensor([650, 20]), torch.tensor([0, 3])
+    e = dec(cu(x), cu(t), cu(sem), cu(si)).cpu()
+    ref64 = O.decoder_forward(O.cast_sd(sd, torch.float64), x.double(), t, sem, si, window=window)
+    ref32 = O.decoder_forward(sd, x, t, sem, si, window=window)
+    ours, theirs = max_abs(e, ref64), max_abs(ref32, ref64)
+    print(f"window {window}, all scores << 0: ours vs fp64 {ours:.2e}, oracle fp32 vs fp64 {theirs:.2e}")
+    assert bool(torch.isfinite(e).all())
+    assert ours < max(5e-4, 20 * theirs)
+
+
 @pytest.mark.parametrize("B,S", [(1, 1), (3, 7), (5, 16), (2, 100)])
 def test_forward_small_and_odd_shapes(B, S):
     """Shortest possible utterance (S=1 -> T=2), lengths that are not multiples of any tile, odd batches."""
