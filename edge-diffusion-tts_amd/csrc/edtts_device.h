@@ -369,7 +369,9 @@ EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, cons
     // diagonal guarantees that the (peeled) first step finds a visible key in every such row and can set its reference point.
     // (With the band start not on a chunk boundary -- windows that are not multiples of 16 -- chunk 0 is fully masked for some
     // rows that do see later keys; a reference left at 0 there underflows every exp2 when all scores are far below zero.)
-    q.cdiag = SELF ? ((q.m0 >> 4) - q.kt_lo) / CH : 0;
+    // Only needed when the band start is not on a chunk boundary (else chunk 0 already shows a key to every row that has one).
+    const bool off_grid = SELF && window >= 0 && (q.m0 - window > (q.kt_lo << 4));
+    q.cdiag = off_grid ? ((q.m0 >> 4) - q.kt_lo) / CH : 0;
     if (q.cdiag >= q.nchunk) q.cdiag = q.nchunk - 1;  // half entirely past the end of the utterance
     q.klim = (q.kt_hi << 4) < nkeys ? (q.kt_hi << 4) : nkeys;  // keys >= klim are never valid
 #pragma unroll
