@@ -1,5 +1,6 @@
 """GPU parity tests: the product path (Python API -> ctypes -> libedtts_hip.so -> gfx950 kernels) against the
 reference's golden vectors and the CPU oracle.  Run on the GPU box: python -m pytest tests -m gpu."""
+import numpy as np
 import pytest
 import torch
 
@@ -322,6 +323,33 @@ def test_small_window_all_scores_far_below_zero(window):
     print(f"window {window}, all scores << 0: ours vs fp64 {ours:.2e}, oracle fp32 vs fp64 {theirs:.2e}")
     assert bool(torch.isfinite(e).all())
     assert ours < max(5e-4, 20 * theirs)
+
+
+def test_forward_random_geometries():
+    """Seeded sweep over (B, T, S, window): ragged lengths, windows on and off the 16-key tile grid, windows larger than the
+    utterance, full attention -- the mask / chunk-order / tile-clamping logic against the oracle."""
+    rng = np.random.default_rng(20260101)
+    worst = 0.0
+    for case in range(14):
+        B = int(rng.integers(1, 4))
+        S = int(rng.integers(1, 110))
+        T = 2 * S
+        window = [None, int(rng.integers(1, 100)), int(rng.integers(1, 20)), 64][case % 4]
+        cfg = CFG(device=DEV, attn_window_size=window)
+        sd = synth_state_dict(cfg, 5 + case % 3)
+        dec = EdgeDiffusionDecoder(cfg)
+        dec.load_state_dict(sd)
+        dec = dec.to(DEV).eval()
+        gen = torch.Generator().manual_seed(100 + case)
+        x = torch.randn(B, T, 80, generator=gen)
+        sem = torch.randint(0, 512, (B, S), generator=gen)
+        t = torch.randint(0, 1000, (B,), generator=gen)
+        si = torch.randint(0, 16, (B,), generator=gen)
+        e = dec(cu(x), cu(t), cu(sem), cu(si)).cpu()
+        err = max_abs(e, O.decoder_forward(sd, x, t, sem, si, window=window))
+        worst = max(worst, err)
+        assert err < FWD_TOL, (case, B, T, S, window, err)
+    print(f"random geometries: worst max-abs {worst:.2e}")
 
 
 @pytest.mark.parametrize("B,S", [(1, 1), (3, 7), (5, 16), (2, 100)])
