@@ -541,9 +541,10 @@ EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, cons
       //
       // Online softmax with a DEFERRED running maximum: fp32 accumulators have ~2^127 of headroom, so the reference point m only
       // has to move when a chunk exceeds it by more than 2^kDefer; until then P = 2^(s - m) <= 2^kDefer and neither O nor the
-      // row sums need rescaling (softmax is invariant to m).  Chunk 0 sets m to its row maximum; from chunk 1 on the scores come
-      // out of the MFMAs as s - m (see qk) and the wave-uniform rescale branch is taken only when some row jumps by more than
-      // kDefer octaves -- the read-modify-write of O, the cross-lane max and the subtraction of m stay out of the common path.
+      // row sums need rescaling (softmax is invariant to m).  The first step sets m to its chunk's row maximum; from the second
+      // step on the scores come out of the MFMAs as s - m (see qk) and the wave-uniform rescale branch is taken only when some
+      // row jumps by more than kDefer octaves -- the read-modify-write of O, the cross-lane max and the subtraction of m stay
+      // out of the common path.  (Chunk order: see Geo::cdiag.)
       f4 S[CH][2];
       f4 NM[2] = {splat(0.f), splat(0.f)};
       float nm[2] = {0.f, 0.f};
