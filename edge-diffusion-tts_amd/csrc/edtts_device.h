@@ -337,8 +337,6 @@ EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, cons
   constexpr int DH = C::DH, DFULL = C::DFULL, DREM = C::DREM, DT = C::DT, H = C::H, CH = kChunk, NF = C::NF;
   constexpr int NHALF = C::NHALF;
   const int fq = lane & 15, g = lane >> 4;
-  // softmax in base 2: p = 2^((s - m) * c), c = log2(e) / sqrt(d)
-  const float c2 = 1.4426950408889634f * rsqrtf((float)DH);
   const float NEG_INF = -__builtin_inff();
   // Row map of the 8-feature remainder tile of V^T (head_dim % 16 == 8): MFMA row i = 4*gO + reg of the P V product carries
   // feature 2*gO + reg for reg < 2 (rows with reg >= 2 repeat a valid row and are never read), so the valid features of O^T land
@@ -520,15 +518,10 @@ EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, cons
     for (int hf = 0; hf < NHALF; ++hf) {
       const Geo& q = geo[hf];
       if (hf > 0) prefetch(q, hd, hf);
-      // pre-scale q by log2(e)/sqrt(d): the scores then come out of the MFMA in the exp2 domain
-      f4 qa[2][DFULL > 0 ? DFULL : 1];
-      f2 qr[2];
-#pragma unroll
-      for (int ft = 0; ft < 2; ++ft) {
-#pragma unroll
-        for (int a = 0; a < DFULL; ++a) qa[ft][a] = qa_n[ft][a] * c2;
-        if (DREM) qr[ft] = qr_n[ft] * c2;
-      }
+      // (q arrives pre-scaled by log2(e)/sqrt(d) -- the factor is folded into the packed query weights -- so the scores come
+      // out of the MFMA in the exp2 domain, and the prefetched fragments are used as they are)
+      const auto& qa = qa_n;
+      const auto& qr = qr_n;
       f4 lvec[2] = {splat(0.f), splat(0.f)};  // per-lane partial row sums (reduced over r and the lane groups at the end)
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) O[dt][2 * hf] = O[dt][2 * hf + 1] = splat(0.f);

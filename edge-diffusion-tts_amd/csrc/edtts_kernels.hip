@@ -166,6 +166,8 @@ struct PackArgs {
   int dstmode;       // 0 n-major, 1 k-major, 2 ffn-up inside the ffn stream, 3 ffn-down inside the ffn stream
   int DH, DHP;
   float* dst;
+  int scale_rows;    // rows [0, scale_rows) are multiplied by `scale` (the attention query rows carry log2(e)/sqrt(head_dim))
+  float scale;
 };
 __global__ void k_pack_gemm(PackArgs a) {
   const int tile = blockIdx.x, lane = threadIdx.x;
@@ -200,7 +202,7 @@ __global__ void k_pack_gemm(PackArgs a) {
         col = hd * a.DH + full + 2 * (kk >> 2) + (kk & 3);
       }
     }
-    v[r] = (rok && cok) ? a.src[(size_t)row * a.ld + col] : 0.f;
+    v[r] = (rok && cok) ? a.src[(size_t)row * a.ld + col] * (row < a.scale_rows ? a.scale : 1.0f) : 0.f;
   }
   size_t frag;
   const int S3 = 2 * a.KT + a.NT;  // fragments per ffn hidden tile (valid when KT == NT == HT for mode 2; see host)
@@ -1179,8 +1181,8 @@ int edtts_workspace_bytes(const EdttsDims* dims, int B, int T, int S, int cond_r
 }
 
 static int pack_gemm(hipStream_t st, const float* src, int ld, int N, int K, int NT, int KT, int rowmode, int colmode,
-                     int dstmode, int DH, int DHP, float* dst) {
-  PackArgs p{src, ld, N, K, NT, KT, rowmode, colmode, dstmode, DH, DHP, dst};
+                     int dstmode, int DH, int DHP, float* dst, int scale_rows = 0, float scale = 1.0f) {
+  PackArgs p{src, ld, N, K, NT, KT, rowmode, colmode, dstmode, DH, DHP, dst, scale_rows, scale};
   hipLaunchKernelGGL(k_pack_gemm, dim3(NT * KT), dim3(64), 0, st, p);
   LAUNCH_CHECK("k_pack_gemm");
   return EDTTS_OK;
@@ -1245,11 +1247,13 @@ int edtts_pack_weights(const EdttsDims* dims, const void* const* slots, int n_sl
     TRY(copy_f(st, W(L_KVN_W), blob + y.kvn, R));
     TRY(pack_gemm(st, W(L_KVU_W), R, 2 * H, R, 2 * HT, RT, 0, 0, 0, DH, DHP, blob + y.kvu));
     // fragment stream
-    TRY(pack_gemm(st, W(L_QKV_W), H, 3 * H, H, 3 * HT, HT, 0, 0, 4, DH, DHP, blob + y.s_qkv));  // n-tile pairs
+    // the query rows carry the softmax scale: scores come out of K Q^T in the exp2 domain, log2(e) / sqrt(head_dim)
+    const float qscale = 1.4426950408889634f / sqrtf((float)DH);
+    TRY(pack_gemm(st, W(L_QKV_W), H, 3 * H, H, 3 * HT, HT, 0, 0, 4, DH, DHP, blob + y.s_qkv, H, qscale));  // n-tile pairs
     float* s = blob + y.s_body;
     TRY(pack_gemm(st, W(L_PROJ_W), H, H, lo.HEADS * DHP, HT, KPT, 0, 1, 1, DH, DHP, s));
     s += (size_t)KPT * HT * kFrag;
-    TRY(pack_gemm(st, W(L_QP_W), H, H, H, HT, HT, 0, 0, 4, DH, DHP, s));
+    TRY(pack_gemm(st, W(L_QP_W), H, H, H, HT, HT, 0, 0, 4, DH, DHP, s, H, qscale));
     s += (size_t)HT * HT * kFrag;
     TRY(pack_gemm(st, W(L_OP_W), H, H, lo.HEADS * DHP, HT, KPT, 0, 1, 1, DH, DHP, s));
     s += (size_t)KPT * HT * kFrag;
