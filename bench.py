@@ -50,7 +50,7 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="utterances per GPU")
     ap.add_argument("--frames", type=int, default=512, help="mel frames per utterance (T = 2*S)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-batch", type=int, default=48)
+    ap.add_argument("--cpu-sample-batch", type=int, default=128)  # ~10-15 s of CPU work on 16 threads
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
