@@ -753,7 +753,8 @@ EDTTS_DEV void lms_elem(float x, float out, float h_new, float h_old, const LmsC
 
 // Philox4x32-10 counter-based generator (Salmon et al., SC'11) -> four standard normals per call (Box-Muller).
 // counter = (element index lo, hi, step, 0), key = (seed lo, hi): every (seed, step, element) gets its own stream, so the
-// result does not depend on how elements are distributed over waves / GPUs.
+// result does not depend on how elements are distributed over waves / GPUs PROVIDED the caller passes the GLOBAL element index
+// (the sharded callers add their shard's first-element offset: KArgs::philox_base, edtts_randn's elem_offset).
 EDTTS_DEV f4 philox_normal4(unsigned long long seed, unsigned step, unsigned long long index) {
   unsigned c0 = (unsigned)index, c1 = (unsigned)(index >> 32), c2 = step, c3 = 0u;
   unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);

@@ -252,6 +252,7 @@ struct CondArgs {
   unsigned ada1T[kMaxLayers], ada1b[kMaxLayers], ada3T[kMaxLayers], ada3b[kMaxLayers];  // offsets (floats) -- blob < 16 GiB
   float* cond;   // [rows][L][2][2H]
   float* tcond;  // [rows][H] scratch
+  unsigned* err; // index-error word of the workspace
 };
 // stage 1: t_cond row = Linear(GELU(Linear(sinus(t)))) + step_emb[step_idx]      (one block per row)
 __global__ __launch_bounds__(256) void k_cond_mlp(CondArgs a) {
@@ -275,7 +276,10 @@ __global__ __launch_bounds__(256) void k_cond_mlp(CondArgs a) {
   long sidx = -1;
   if (a.use_host ? a.host_has_step : (a.step_idx != nullptr)) {
     sidx = a.use_host ? (long)a.step_host[row] : (long)a.step_idx[row];
-    sidx = sidx < 0 ? 0 : (sidx >= a.n_step ? a.n_step - 1 : sidx);  // the reference raises IndexError (F7); clamp, never fault
+    if (sidx < 0 || sidx >= a.n_step) {  // the reference raises IndexError (F7): clamp (never fault), leave a mark for the host
+      if (tid == 0) atomicOr(a.err, (unsigned)EDTTS_IDX_STEP);
+      sidx = sidx < 0 ? 0 : a.n_step - 1;
+    }
   }
   for (int n = tid; n < H; n += blockDim.x) {
     float acc = a.t3b[n];
@@ -332,6 +336,7 @@ struct KArgs {
   float p_coef1, p_coef2, p_sd;           // DDPM tail scalars (schedule.py:227-237)
   const float* noise;                     // DDPM tail: injected noise [B,T,MEL] of this step, or null -> Philox
   unsigned long long seed;
+  unsigned long long philox_base;         // global element index of this shard's element 0 (batch_offset * T * MEL)
   unsigned step;
   LmsCoef lms;                            // multistep-solver tail
   const float *h_new, *h_old;             // previous x0 predictions (may alias x0_hist: read before write, same lane)
@@ -428,18 +433,15 @@ __global__ __launch_bounds__(C::THREADS) void k_prologue(KArgs a) {
     for (int t = 0; t < C::MT; ++t)
       xin[t][ft] = f < a.T ? ldg4(a.x + ((size_t)b * a.T + f) * C::MEL + 16 * t + 4 * g) : splat(0.f);
   }
-  // h = in_proj(x) + bias + pe   (decoder.py:96-97).  The HT*MT in_proj fragments head the kernel's stream (n-tile pairs per
-  // k-tile) and are consumed as ONE ring phase, so they are prefetched like every other weight.
+  // h = (in_proj(x) + bias) + pe   (decoder.py:96-97).  The HT*MT in_proj fragments head the kernel's stream (n-tile pairs per
+  // k-tile) and are consumed as ONE ring phase, so they are prefetched like every other weight.  The accumulators start at the
+  // bias; the positional row is added after the GEMM (one rounding at its magnitude, as in the reference).
   f4 h[C::HT][NF];
 #pragma unroll
   for (int nt = 0; nt < C::HT; ++nt) {
     const f4 bias = ldg4(a.inp_b + 16 * nt + 4 * g);
 #pragma unroll
-    for (int ft = 0; ft < NF; ++ft) {
-      int f = m0 + 16 * ft + fq;
-      f = f < a.max_pos ? f : a.max_pos - 1;
-      h[nt][ft] = bias + ldg4(a.pe + (size_t)f * C::H + 16 * nt + 4 * g);  // embeddings.py:142
-    }
+    for (int ft = 0; ft < NF; ++ft) h[nt][ft] = bias;
   }
   {
     constexpr int N = C::HT * C::MT;
@@ -462,6 +464,13 @@ __global__ __launch_bounds__(C::THREADS) void k_prologue(KArgs a) {
         ring.template refill_after<N>(i + 1);
       }
     ring.advance(N);
+  }
+#pragma unroll
+  for (int ft = 0; ft < NF; ++ft) {
+    int f = m0 + 16 * ft + fq;
+    f = f < a.max_pos ? f : a.max_pos - 1;
+#pragma unroll
+    for (int nt = 0; nt < C::HT; ++nt) h[nt][ft] += ldg4(a.pe + (size_t)f * C::H + 16 * nt + 4 * g);  // embeddings.py:142
   }
   {  // (padding waves have returned)
     float* hp = a.h + ((size_t)b * a.Tp + m0 + fq) * C::H + 4 * g;
@@ -517,57 +526,81 @@ __global__ __launch_bounds__(C::THREADS) void k_layer(KArgs a) {
   WStream<C> ring;
   ring.prime(a.stream, lane);
 
-  // residual stream tile, + self-attention projection bias (attention.py:123)
+  // Residual stream: every branch (self-attention, cross-attention, FFN) is accumulated by the MFMAs into a tile that starts at the
+  // branch's bias (or 0) and is added to the residual ONCE at the end of the branch -- as the reference does (x = x + f(x),
+  // transformer.py:146,151,158).  Accumulating the ~640 products of a layer straight into the residual would round each partial
+  // sum at the residual's magnitude (|h| ~ 2..8, ulp 2.4e-7 .. 4.8e-7) instead of the branch's (~0.1..1): measured, that alone put
+  // the decoder's fp32 error at 5.6x the reference's own fp32-vs-fp64 distance.  While a branch accumulates, the residual tile is
+  // parked in this wave's rows of the h buffer (owned by the wave: no other wave reads them during the launch) rather than in
+  // 16*NF*HT more registers.
   f4 h[C::HT][NF];
-  {
-    const float* hp = a.h + rowbase * C::H + 4 * g;
+  float* const hp = a.h + rowbase * C::H + 4 * g;
+  auto park_h = [&]() {  // (padding waves have returned)
 #pragma unroll
-    for (int nt = 0; nt < C::HT; ++nt) {
-      f4 pb = splat(0.f);
-      if (PART != PART_FFN) pb = ldg4(a.proj_b + 16 * nt + 4 * g);
+    for (int nt = 0; nt < C::HT; ++nt)
 #pragma unroll
-      for (int ft = 0; ft < NF; ++ft) h[nt][ft] = ldg4(hp + 16 * nt + (size_t)ft * 16 * C::H) + pb;
-    }
-  }
+      for (int ft = 0; ft < NF; ++ft) stg4(hp + 16 * nt + (size_t)ft * 16 * C::H, h[nt][ft]);
+  };
+  auto add_parked_h = [&]() {  // h (the finished branch) += residual
+#pragma unroll
+    for (int nt = 0; nt < C::HT; ++nt)
+#pragma unroll
+      for (int ft = 0; ft < NF; ++ft) h[nt][ft] += ldg4(hp + 16 * nt + (size_t)ft * 16 * C::H);
+  };
 #ifdef EDTTS_DIAG
 #define DIAG_ON(bit) (!(a.diag_skip & (bit)))
 #else
 #define DIAG_ON(bit) true
 #endif
   // ---- x = x + attn(norm1(x, cond))   (transformer.py:142-146; q/k/v were produced by the previous kernel) ----
-  if (PART != PART_FFN && DIAG_ON(1)) {
-    QGlobal ql{a.q + rowbase * C::H, C::H};
-    attention_fused<C, true>(ql, a.k + (size_t)b * a.Tp * C::H, a.vT + (size_t)b * C::VR * a.Tp, a.Tp, a.T, a.window, m0,
-                             lane, ring, h);
+  if (PART != PART_FFN) {
+    // branch tile starts at the projection bias (attention.py:123); the residual itself stays in memory until the branch is done
+#pragma unroll
+    for (int nt = 0; nt < C::HT; ++nt) {
+      const f4 pb = ldg4(a.proj_b + 16 * nt + 4 * g);
+#pragma unroll
+      for (int ft = 0; ft < NF; ++ft) h[nt][ft] = pb;
+    }
+    if (DIAG_ON(1)) {
+      QGlobal ql{a.q + rowbase * C::H, C::H};
+      attention_fused<C, true>(ql, a.k + (size_t)b * a.Tp * C::H, a.vT + (size_t)b * C::VR * a.Tp, a.Tp, a.T, a.window, m0,
+                               lane, ring, h);
+    }
+    add_parked_h();
+  } else {
+#pragma unroll
+    for (int nt = 0; nt < C::HT; ++nt)
+#pragma unroll
+      for (int ft = 0; ft < NF; ++ft) h[nt][ft] = ldg4(hp + 16 * nt + (size_t)ft * 16 * C::H);
   }
   // ---- x = x + cross_attn(norm2(x), context)   (transformer.py:151, mla.py:118-194) --------------------------
   if (PART != PART_FFN && DIAG_ON(2)) {
-    f4 hn[C::HT][NF];
-    rms_norm_tile<C::HT, NF>(h, a.n2w, nullptr, g, hn);
-    for (int nt = 0; nt < C::HT; nt += 2) {
-      f4 acc[2][NF];
+    {
+      f4 hn[C::HT][NF];
+      rms_norm_tile<C::HT, NF>(h, a.n2w, nullptr, g, hn);
+      park_h();
+      for (int nt = 0; nt < C::HT; nt += 2) {
+        f4 acc[2][NF];
 #pragma unroll
-      for (int ft = 0; ft < NF; ++ft) acc[0][ft] = acc[1][ft] = splat(0.f);
-      gemm_phase_pair<C::HT>(ring, hn, acc[0], acc[1]);
+        for (int ft = 0; ft < NF; ++ft) acc[0][ft] = acc[1][ft] = splat(0.f);
+        gemm_phase_pair<C::HT>(ring, hn, acc[0], acc[1]);
 #pragma unroll
-      for (int u = 0; u < 2; ++u)
+        for (int u = 0; u < 2; ++u)
 #pragma unroll
-        for (int ft = 0; ft < NF; ++ft) stg4(qtile + (16 * ft + fq) * C::QLD + 16 * (nt + u) + 4 * g, acc[u][ft]);
+          for (int ft = 0; ft < NF; ++ft) stg4(qtile + (16 * ft + fq) * C::QLD + 16 * (nt + u) + 4 * g, acc[u][ft]);
+      }
     }
-  }
-  if (PART != PART_FFN && DIAG_ON(2)) {
+#pragma unroll
+    for (int nt = 0; nt < C::HT; ++nt)
+#pragma unroll
+      for (int ft = 0; ft < NF; ++ft) h[nt][ft] = splat(0.f);
     QLds ql{qtile + fq * C::QLD, C::QLD};
     attention_fused<C, false>(ql, a.kc + (size_t)b * a.Sp * C::H, a.vcT + (size_t)b * C::VR * a.Sp, a.Sp, a.S, -1, m0, lane,
                               ring, h);
+    add_parked_h();
   }
   if (PART == PART_ATTN) {  // hand the residual tile to the FFN half
-    {  // (padding waves have returned)
-      float* hp = a.h + rowbase * C::H + 4 * g;
-#pragma unroll
-      for (int nt = 0; nt < C::HT; ++nt)
-#pragma unroll
-        for (int ft = 0; ft < NF; ++ft) stg4(hp + 16 * nt + (size_t)ft * 16 * C::H, h[nt][ft]);
-    }
+    park_h();
     return;
   }
   // ---- x = x + ffn(norm3(x, cond))   (transformer.py:154-158, :13-49) ----------------------------------------
@@ -575,11 +608,12 @@ __global__ __launch_bounds__(C::THREADS) void k_layer(KArgs a) {
     f4 hn[C::HT][NF];
     const float* mod = a.cond + (size_t)b * a.cond_bstride + ((size_t)a.layer * 2 + 1) * 2 * C::H;
     rms_norm_tile<C::HT, NF>(h, a.n3w, mod, g, hn);
+    park_h();
 #pragma unroll
     for (int nt = 0; nt < C::HT; ++nt) {
       const f4 db = ldg4(a.down_b + 16 * nt + 4 * g);
 #pragma unroll
-      for (int ft = 0; ft < NF; ++ft) h[nt][ft] += db;
+      for (int ft = 0; ft < NF; ++ft) h[nt][ft] = db;
     }
     for (int j = 0; j < 2 * C::HT; ++j) {
       const f4 vb = ldg4(a.up_b + 32 * j + 4 * g), gb = ldg4(a.up_b + 32 * j + 16 + 4 * g);
@@ -611,6 +645,7 @@ __global__ __launch_bounds__(C::THREADS) void k_layer(KArgs a) {
 #endif
       ktile_phase<C::HT>(ring, act, h);
     }
+    add_parked_h();
   }
   // ---- tail ---------------------------------------------------------------------------------------------------
   if (!DIAG_ON(8)) return;
@@ -663,7 +698,7 @@ __global__ __launch_bounds__(C::THREADS) void k_layer(KArgs a) {
         } else if (TAIL == TAIL_DDPM) {
           // ancestral DDPM update (schedule.py:222-238): mean + [t>0] * sqrt(posterior variance) * noise
           const f4 xv = ldg4(a.x + idx);
-          const f4 nz = a.noise ? ldg4(a.noise + idx) : philox_normal4(a.seed, a.step, idx >> 2);
+          const f4 nz = a.noise ? ldg4(a.noise + idx) : philox_normal4(a.seed, a.step, (a.philox_base + idx) >> 2);
           const DdpmCoef cf{a.p_coef1, a.p_coef2, a.p_sd};
           f4 xp;
 #pragma unroll
@@ -699,6 +734,7 @@ struct CtxArgs {
   const float* blob;
   unsigned kvd[kMaxLayers], kvn[kMaxLayers], kvu[kMaxLayers];
   float *kc, *vcT;  // [L][B][Sp][H], [L][B][VR][Sp]
+  unsigned* err;    // index-error word of the workspace
 };
 template <class C>  // always instantiated with NF = 2 (32 context tokens per wave)
 __global__ __launch_bounds__(64 * kCtxWaves) void k_ctx(CtxArgs a) {
@@ -735,7 +771,10 @@ __global__ __launch_bounds__(64 * kCtxWaves) void k_ctx(CtxArgs a) {
     for (int ft = 0; ft < 2; ++ft) {
       const int s = m0 + 16 * ft + fq;
       long tk = s < a.S ? (long)a.sem_idx[(size_t)b * a.S + s] : 0;
-      tk = tk < 0 ? 0 : (tk >= a.n_tok ? a.n_tok - 1 : tk);  // nn.Embedding would raise; clamp, never fault
+      if (tk < 0 || tk >= a.n_tok) {  // nn.Embedding would raise IndexError: clamp (never fault) and leave a mark for the host
+        atomicOr(a.err, (unsigned)EDTTS_IDX_SEM);
+        tk = tk < 0 ? 0 : a.n_tok - 1;
+      }
       const float* row = a.tok + (size_t)tk * C::H + 4 * g;
 #pragma unroll
       for (int nt = 0; nt < C::HT; ++nt) ctx[nt][ft] = ldg4(row + 16 * nt);  // decoder.py:88
@@ -924,7 +963,7 @@ __global__ void k_dsconv_norm(const float* z, const float* stats, const float* g
 // host side
 // =========================================================================================================
 struct Workspace {
-  size_t h, q, k, vT, kc, vcT, cond, total;  // offsets in floats
+  size_t err, h, q, k, vT, kc, vcT, cond, total;  // offsets in floats (err = 0: the index-error word heads every workspace)
   int Tp, Sp, VR;
 };
 // frame tiles per wave of the default-decoder instance.  Measured (B=256, T=512): NF=4 lifts the FFN phase from 80 % to 88 %
@@ -958,6 +997,7 @@ static void make_workspace(const Layout& lo, int B, int T, int S, int cond_rows,
   w->VR = (lo.HEADS - 1) * lo.DH + lo.DHP;
   size_t o = 0;
   auto take = [&](size_t n) { size_t r = o; o = align64(o + n); return r; };
+  w->err = take(64);  // word 0: EDTTS_IDX_* bits set by kernels that had to clamp an out-of-range index
   w->h = take((size_t)B * w->Tp * H);
   w->q = take((size_t)2 * B * w->Tp * H);  // two sets each (ping-pong between layers)
   w->k = take((size_t)2 * B * w->Tp * H);
@@ -991,6 +1031,7 @@ struct Launcher {
       a.kvd[l] = (unsigned)lo.layer[l].kvd; a.kvn[l] = (unsigned)lo.layer[l].kvn; a.kvu[l] = (unsigned)lo.layer[l].kvu;
     }
     a.kc = wsb + ws.kc; a.vcT = wsb + ws.vcT;
+    a.err = reinterpret_cast<unsigned*>(wsb + ws.err);
     hipLaunchKernelGGL(k_ctx<C2>, dim3(ctx_grid(B, ws.Sp)), dim3(64 * kCtxWaves), 0, st, a);
     LAUNCH_CHECK("k_ctx");
     return EDTTS_OK;
@@ -1013,7 +1054,7 @@ struct Launcher {
   // one decoder forward given conditioning rows + context cache already in the workspace
   struct DdpmStep {
     const float* noise;
-    unsigned long long seed;
+    unsigned long long seed, base;
     unsigned step;
   };
   struct LmsStep {
@@ -1057,7 +1098,7 @@ struct Launcher {
       } else if (tail == TAIL_DDPM) {
         a.x_prev = x_prev;
         a.p_coef1 = coef[0]; a.p_coef2 = coef[1]; a.p_sd = coef[2];
-        a.noise = ddpm->noise; a.seed = ddpm->seed; a.step = ddpm->step;
+        a.noise = ddpm->noise; a.seed = ddpm->seed; a.philox_base = ddpm->base; a.step = ddpm->step;
       } else {
         a.x_prev = x_prev; a.x0 = x0;
         a.c_s1m = coef[0]; a.c_sab = coef[1]; a.c_sabp = coef[2]; a.c_dir = coef[3];
@@ -1097,8 +1138,12 @@ struct Launcher {
 
   static int set_attrs() {
     // kernels with > 64 KiB of dynamic LDS need the opt-in attribute
-    static bool done = false;
-    if (done) return EDTTS_OK;
+    // (the attribute is per device: one flag per device ordinal, so that a process driving several GPUs opts in on each)
+    static bool done[64] = {};
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) return fail(EDTTS_ERR_UNSUPPORTED, "device ordinal %d out of range", dev);
+    if (done[dev]) return EDTTS_OK;
     const int lds = (int)layer_lds();
     if (SPLIT) {
       HIP_TRY(hipFuncSetAttribute((const void*)k_layer<C, TAIL_QKV, PART_ATTN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -1109,7 +1154,7 @@ struct Launcher {
       HIP_TRY(hipFuncSetAttribute((const void*)k_layer<C, TAIL_DDPM, PART_ALL>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
       HIP_TRY(hipFuncSetAttribute((const void*)k_layer<C, TAIL_LMS, PART_ALL>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     }
-    done = true;
+    done[dev] = true;
     return EDTTS_OK;
   }
 };
@@ -1126,7 +1171,7 @@ struct Launcher {
   } while (0)
 
 static int launch_cond(const Layout& lo, const float* blob, const int64_t* t, const int64_t* step_idx, const int64_t* t_host,
-                       int rows, float* cond, hipStream_t st) {
+                       int rows, float* cond, float* wsb, hipStream_t st) {
   CondArgs a;
   memset(&a, 0, sizeof(a));
   a.t = t; a.step_idx = step_idx; a.H = lo.H; a.L = lo.L; a.n_step = lo.NSTEP;
@@ -1142,6 +1187,7 @@ static int launch_cond(const Layout& lo, const float* blob, const int64_t* t, co
     a.ada3T[l] = (unsigned)lo.layer[l].ada3T; a.ada3b[l] = (unsigned)lo.layer[l].ada3b;
   }
   a.cond = cond;
+  a.err = reinterpret_cast<unsigned*>(wsb);  // Workspace::err = 0
   a.tcond = cond + (size_t)rows * lo.L * 2 * 2 * lo.H;  // scratch right behind the rows (see make_workspace)
   hipLaunchKernelGGL(k_cond_mlp, dim3(rows), dim3(256), 2 * lo.H * sizeof(float), st, a);
   LAUNCH_CHECK("k_cond_mlp");
@@ -1283,7 +1329,7 @@ int edtts_decoder_forward(const EdttsDims* dims, const void* packed, void* works
   float* wsb = (float*)workspace;
   Workspace ws;
   make_workspace(lo, B, T, S, B, &ws);
-  TRY(launch_cond(lo, blob, t, step_idx, nullptr, B, wsb + ws.cond, st));
+  TRY(launch_cond(lo, blob, t, step_idx, nullptr, B, wsb + ws.cond, wsb, st));
   const int bstride = lo.L * 2 * 2 * lo.H;
   EDTTS_DISPATCH(lo, {
     TRY(Launcher<C>::set_attrs());
@@ -1310,7 +1356,7 @@ int edtts_generate(const EdttsDims* dims, const void* packed, void* workspace, i
   float* wsb = (float*)workspace;
   Workspace ws;
   make_workspace(lo, B, T, S, num_steps, &ws);
-  TRY(launch_cond(lo, blob, nullptr, nullptr, timesteps_host, num_steps, wsb + ws.cond, st));
+  TRY(launch_cond(lo, blob, nullptr, nullptr, timesteps_host, num_steps, wsb + ws.cond, wsb, st));
   const size_t row = (size_t)lo.L * 2 * 2 * lo.H;
   EDTTS_DISPATCH(lo, {
     TRY(Launcher<C>::set_attrs());
@@ -1339,7 +1385,7 @@ int edtts_sample_multistep(const EdttsDims* dims, const void* packed, void* work
   float* wsb = (float*)workspace;
   Workspace ws;
   make_workspace(lo, B, T, S, num_steps, &ws);
-  TRY(launch_cond(lo, blob, nullptr, nullptr, timesteps_host, num_steps, wsb + ws.cond, st));
+  TRY(launch_cond(lo, blob, nullptr, nullptr, timesteps_host, num_steps, wsb + ws.cond, wsb, st));
   const size_t row = (size_t)lo.L * 2 * 2 * lo.H;
   const size_t per = (size_t)B * T * lo.MEL;
   EDTTS_DISPATCH(lo, {
@@ -1364,11 +1410,12 @@ int edtts_sample_multistep(const EdttsDims* dims, const void* packed, void* work
 
 int edtts_sample_ddpm(const EdttsDims* dims, const void* packed, void* workspace, int B, int S, const int64_t* sem_idx,
                       const float* x_T, int num_steps, const int64_t* t_all, const float* coef_host, const float* noise_all,
-                      uint64_t seed, float* x_out, void* stream) {
+                      uint64_t seed, int64_t batch_offset, float* x_out, void* stream) {
   Layout lo;
   TRY(make_layout(dims, &lo));
   if (!packed || !workspace || !sem_idx || !x_T || !t_all || !coef_host || !x_out) return fail(EDTTS_ERR_ARG, "NULL pointer argument");
   if (num_steps < 1) return fail(EDTTS_ERR_ARG, "num_steps=%d < 1", num_steps);
+  if (batch_offset < 0) return fail(EDTTS_ERR_ARG, "batch_offset=%lld < 0", (long long)batch_offset);
   const int T = 2 * S;
   TRY(check_shapes(lo, B, T, S));
   hipStream_t st = (hipStream_t)stream;
@@ -1376,14 +1423,15 @@ int edtts_sample_ddpm(const EdttsDims* dims, const void* packed, void* workspace
   float* wsb = (float*)workspace;
   Workspace ws;
   make_workspace(lo, B, T, S, num_steps, &ws);
-  TRY(launch_cond(lo, blob, t_all, nullptr, nullptr, num_steps, wsb + ws.cond, st));  // step_idx = None (train.py:155 usage)
+  TRY(launch_cond(lo, blob, t_all, nullptr, nullptr, num_steps, wsb + ws.cond, wsb, st));  // step_idx = None (train.py:155 usage)
   const size_t row = (size_t)lo.L * 2 * 2 * lo.H;
   const size_t per_step = (size_t)B * T * lo.MEL;
   EDTTS_DISPATCH(lo, {
     TRY(Launcher<C>::set_attrs());
     TRY(Launcher<C>::ctx(lo, blob, ws, wsb, B, S, sem_idx, nullptr, st));
     for (int i = 0; i < num_steps; ++i) {
-      typename Launcher<C>::DdpmStep ds{noise_all ? noise_all + (size_t)i * per_step : nullptr, (unsigned long long)seed, (unsigned)i};
+      typename Launcher<C>::DdpmStep ds{noise_all ? noise_all + (size_t)i * per_step : nullptr, (unsigned long long)seed,
+                                        (unsigned long long)batch_offset * T * lo.MEL, (unsigned)i};
       TRY(Launcher<C>::forward(lo, blob, ws, wsb, B, T, S, dims->window, i == 0 ? x_T : x_out, wsb + ws.cond + i * row, 0, TAIL_DDPM,
                                nullptr, x_out, nullptr, coef_host + 3 * i, st, &ds));
     }
@@ -1442,6 +1490,39 @@ int edtts_dsconv_forward(const float* x, const float* dw, const float* pw, const
   hipLaunchKernelGGL(k_dsconv_norm, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, z, stats, gn_w, gn_b, C_out, T, groups,
                      total, y);
   LAUNCH_CHECK("k_dsconv_norm");
+  return EDTTS_OK;
+}
+
+// standard normals from the Philox stream of (seed, stream_id), element i of the GLOBAL tensor at out[i - elem_offset]
+__global__ __launch_bounds__(256) void k_randn(float* out, size_t n, unsigned long long seed, unsigned stream_id,
+                                               unsigned long long elem_offset, float scale) {
+  const size_t n4 = n >> 2;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    f4 v = philox_normal4(seed, stream_id, (elem_offset >> 2) + i);
+    stg4(out + 4 * i, v * scale);
+  }
+}
+
+int edtts_randn(float* out, size_t n, uint64_t seed, uint32_t stream_id, uint64_t elem_offset, float scale, void* stream) {
+  if (!out) return fail(EDTTS_ERR_ARG, "NULL pointer argument");
+  if ((n & 3) || (elem_offset & 3)) return fail(EDTTS_ERR_ARG, "n=%zu and elem_offset=%llu must be multiples of 4", n, (unsigned long long)elem_offset);
+  if (n == 0) return EDTTS_OK;
+  size_t bx = (n / 4 + 255) / 256;
+  if (bx > 4096) bx = 4096;
+  hipLaunchKernelGGL(k_randn, dim3((unsigned)bx), dim3(256), 0, (hipStream_t)stream, out, n, (unsigned long long)seed, (unsigned)stream_id,
+                     (unsigned long long)elem_offset, scale);
+  LAUNCH_CHECK("k_randn");
+  return EDTTS_OK;
+}
+
+int edtts_index_errors(void* workspace, int* flags_host, void* stream) {
+  if (!workspace || !flags_host) return fail(EDTTS_ERR_ARG, "NULL pointer argument");
+  hipStream_t st = (hipStream_t)stream;
+  unsigned v = 0;
+  HIP_TRY(hipMemcpyAsync(&v, workspace, sizeof(v), hipMemcpyDeviceToHost, st));  // Workspace::err = 0
+  HIP_TRY(hipStreamSynchronize(st));
+  if (v) HIP_TRY(hipMemsetAsync(workspace, 0, sizeof(v), st));
+  *flags_host = (int)v;
   return EDTTS_OK;
 }
 

@@ -52,6 +52,7 @@ class EdgeDiffusionDecoder(nn.Module):
                 _attach(self, key, self._default_init(key, shape), False)
         self._fix_bias_init()
         self.register_buffer("_time_freqs", time_frequencies(H), persistent=False)
+        self._zero_mod = None
         self._packed: Optional[torch.Tensor] = None
         self._packed_sig: Optional[Tuple] = None
         self._workspaces: Dict[Tuple, torch.Tensor] = {}
@@ -140,6 +141,17 @@ class EdgeDiffusionDecoder(nn.Module):
         sd = {k: v for k, v in self.named_parameters()}
         sd.update({k: v for k, v in self.named_buffers()})
         sd["time_freqs"] = sd.pop("_time_freqs")
+        if not self.cfg.use_adaln:
+            # Plain RMSNorm blocks (layers/transformer.py:101-104,119-122,142-157): the kernels' AdaLN slots get the RMSNorm
+            # gain and an all-zero modulation projection, i.e. (1 + scale, shift) = (1, 0) -- y * 1 + 0 is exact in fp32.
+            H = self.cfg.hidden
+            dev = sd["in_proj.weight"].device
+            if self._zero_mod is None or self._zero_mod[0].device != dev:
+                self._zero_mod = (torch.zeros(2 * H, H, device=dev), torch.zeros(2 * H, device=dev))
+            for l in range(self.cfg.layers):
+                for n in ("norm1", "norm3"):
+                    sd[f"layers.{l}.{n}.norm.weight"] = sd.pop(f"layers.{l}.{n}.weight")
+                    sd[f"layers.{l}.{n}.proj.weight"], sd[f"layers.{l}.{n}.proj.bias"] = self._zero_mod
         return sd
 
     def _ensure_packed(self) -> torch.Tensor:

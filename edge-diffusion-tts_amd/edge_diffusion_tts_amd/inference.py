@@ -27,11 +27,15 @@ class EdgeInference:
 
     @torch.no_grad()
     def generate_mel(self, sem_idx: torch.Tensor, num_steps: int = 4, temperature: float = 1.0, *,
-                     x_T: Optional[torch.Tensor] = None, generator: Optional[torch.Generator] = None) -> torch.Tensor:
+                     x_T: Optional[torch.Tensor] = None, generator: Optional[torch.Generator] = None,
+                     seed: Optional[int] = None, batch_offset: int = 0) -> torch.Tensor:
         """Mel [B, 2*S, n_mels] from semantic tokens [B, S] with ``num_steps`` DDIM steps (1..16).
 
-        ``x_T`` / ``generator`` extend the reference signature: the reference draws the start noise from the global
-        device RNG (inference.py:33), which cannot match a CPU run; parity tests inject the oracle's noise instead.
+        ``x_T`` / ``generator`` / ``seed`` extend the reference signature: the reference draws the start noise from the global
+        device RNG (inference.py:33), which cannot match a CPU run; parity tests inject the oracle's noise instead.  With
+        ``seed`` the noise comes from the library's counter-based Philox stream at global row ``batch_offset`` (edtts_randn):
+        a rank holding rows [lo, hi) of a larger batch passes ``batch_offset=lo`` and draws exactly what one GPU would have
+        drawn for those rows.
         """
         if self.encoder is not None and hasattr(self.encoder, "eval"):
             self.encoder.eval()
@@ -40,7 +44,9 @@ class EdgeInference:
         T_out = 2 * S
         dev = sem_idx.device if sem_idx.is_cuda else torch.device(self.device)
         sem_idx = sem_idx.to(dev)
-        if x_T is None:
+        if x_T is None and seed is not None:
+            x_T = native.randn((B, T_out, self.cfg.n_mels), dev, seed, 0, int(batch_offset) * T_out * self.cfg.n_mels, temperature)
+        elif x_T is None:
             x_T = torch.randn(B, T_out, self.cfg.n_mels, device=dev, generator=generator) * temperature
         elif tuple(x_T.shape) != (B, T_out, self.cfg.n_mels):
             raise ValueError(f"x_T must be [{B}, {T_out}, {self.cfg.n_mels}], got {tuple(x_T.shape)}")
@@ -59,13 +65,15 @@ class EdgeInference:
     @torch.no_grad()
     def sample_ddpm(self, sem_idx: torch.Tensor, num_steps: Optional[int] = None, temperature: float = 1.0, *,
                     x_T: Optional[torch.Tensor] = None, noise: Optional[torch.Tensor] = None, seed: int = 0,
-                    generator: Optional[torch.Generator] = None) -> torch.Tensor:
+                    generator: Optional[torch.Generator] = None, batch_offset: int = 0) -> torch.Tensor:
         """Full-schedule ancestral (DDPM) sampler: for t = T-1 ... T-num_steps: eps = decoder(x, t, sem_idx) (step_idx=None),
         x = schedule.ddpm_step(x, t, eps).  This is the loop BASELINE config 5 names; the reference never wrote it (its
         generate_mel cannot exceed 16 steps) but ships both pieces (train.py:155, schedule.py:204-238).
         One C-ABI call: conditioning rows of all steps and the cross-attention cache are built once, the DDPM update is fused
         into every step's last layer.  ``noise`` [num_steps, B, 2S, n_mels] injects the per-step draws (parity); otherwise an
-        in-kernel Philox generator keyed by (seed, step, element) supplies them.  Graph-capturable."""
+        in-kernel Philox generator keyed by (seed, step, global element) supplies them, where ``batch_offset`` is the global index
+        of this call's first utterance (a rank sampling rows [lo, hi) of a batch passes lo: shard-count-invariant draws).
+        Graph-capturable; seed and step are baked into a captured graph, so a replay repeats the same noise."""
         B, S = sem_idx.shape
         T_out = 2 * S
         dev = sem_idx.device if sem_idx.is_cuda else torch.device(self.device)
@@ -88,7 +96,7 @@ class EdgeInference:
             noise = noise.to(device=dev, dtype=torch.float32).contiguous()
         packed = self.decoder._ensure_packed()
         ws = self.decoder.workspace(B, T_out, S, n, dev)
-        return native.sample_ddpm(self.decoder.dims(), packed, ws, sem_idx, x_T, t_all, coefs, noise, seed)
+        return native.sample_ddpm(self.decoder.dims(), packed, ws, sem_idx, x_T, t_all, coefs, noise, seed, batch_offset)
 
     # alias some callers may expect from the task description; not part of the reference API
     generate = generate_mel

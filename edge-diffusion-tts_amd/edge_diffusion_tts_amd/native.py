@@ -19,7 +19,7 @@ EXPORTED_SYMBOLS = (
     "edtts_version", "edtts_last_error", "edtts_num_global_slots", "edtts_num_layer_slots", "edtts_global_slot_name",
     "edtts_layer_slot_name", "edtts_packed_bytes", "edtts_pack_weights", "edtts_workspace_bytes", "edtts_decoder_forward",
     "edtts_ddim_step", "edtts_ddpm_step", "edtts_generate", "edtts_sample_ddpm", "edtts_sample_multistep", "edtts_dsconv_forward", "edtts_profile_enable",
-    "edtts_profile_collect",
+    "edtts_profile_collect", "edtts_randn", "edtts_index_errors",
 )
 
 
@@ -63,7 +63,9 @@ def lib() -> C.CDLL:
     L.edtts_ddpm_step.argtypes = [vp, vp, vp, vp, i32, vp, vp, vp, i32, sz, vp, vp, vp]
     L.edtts_generate.argtypes = [C.POINTER(EdttsDims), vp, vp, i32, i32, vp, vp, i32, C.POINTER(C.c_int64),
                                  C.POINTER(f32), vp, vp, vp]
-    L.edtts_sample_ddpm.argtypes = [C.POINTER(EdttsDims), vp, vp, i32, i32, vp, vp, i32, vp, C.POINTER(f32), vp, C.c_uint64, vp, vp]
+    L.edtts_sample_ddpm.argtypes = [C.POINTER(EdttsDims), vp, vp, i32, i32, vp, vp, i32, vp, C.POINTER(f32), vp, C.c_uint64, C.c_int64, vp, vp]
+    L.edtts_randn.argtypes = [vp, sz, C.c_uint64, C.c_uint32, C.c_uint64, f32, vp]
+    L.edtts_index_errors.argtypes = [vp, C.POINTER(i32), vp]
     L.edtts_sample_multistep.argtypes = [C.POINTER(EdttsDims), vp, vp, i32, i32, i32, vp, vp, vp, i32, C.POINTER(C.c_int64),
                                          C.POINTER(f32), vp, vp, vp, vp]
     L.edtts_dsconv_forward.argtypes = [vp] * 6 + [i32] * 6 + [vp, vp, vp]
@@ -139,6 +141,7 @@ def decoder_forward(dims: EdttsDims, packed: torch.Tensor, workspace: torch.Tens
         C.byref(dims), packed.data_ptr(), workspace.data_ptr(), B, T, S, _dev_ptr(x, torch.float32, "x_t"),
         _dev_ptr(t, torch.int64, "t"), _dev_ptr(step_idx, torch.int64, "step_idx"), _dev_ptr(sem_idx, torch.int64, "sem_idx"),
         _dev_ptr(sem_features, torch.float32, "sem_features"), eps.data_ptr(), _stream(x.device))
+    check_indices(workspace)
     return eps
 
 
@@ -153,11 +156,13 @@ def generate(dims: EdttsDims, packed: torch.Tensor, workspace: torch.Tensor, sem
     x0 = torch.empty_like(x_T)
     lib().edtts_generate(C.byref(dims), packed.data_ptr(), workspace.data_ptr(), B, S, _dev_ptr(sem_idx, torch.int64, "sem_idx"),
                          _dev_ptr(x_T, torch.float32, "x_T"), n, ts, cf, x_work.data_ptr(), x0.data_ptr(), _stream(x_T.device))
+    check_indices(workspace)
     return x0
 
 
 def sample_ddpm(dims: EdttsDims, packed: torch.Tensor, workspace: torch.Tensor, sem_idx: torch.Tensor, x_T: torch.Tensor,
-                t_all: torch.Tensor, coefs: Sequence[Tuple[float, float, float]], noise_all: Optional[torch.Tensor], seed: int) -> torch.Tensor:
+                t_all: torch.Tensor, coefs: Sequence[Tuple[float, float, float]], noise_all: Optional[torch.Tensor], seed: int,
+                batch_offset: int = 0) -> torch.Tensor:
     B, S = sem_idx.shape
     n = t_all.numel()
     flat = [float(v) for c in coefs for v in c]
@@ -165,8 +170,9 @@ def sample_ddpm(dims: EdttsDims, packed: torch.Tensor, workspace: torch.Tensor, 
     out = torch.empty_like(x_T)
     lib().edtts_sample_ddpm(C.byref(dims), packed.data_ptr(), workspace.data_ptr(), B, S, _dev_ptr(sem_idx, torch.int64, "sem_idx"),
                             _dev_ptr(x_T, torch.float32, "x_T"), n, _dev_ptr(t_all, torch.int64, "t_all"), cf,
-                            _dev_ptr(noise_all, torch.float32, "noise"), C.c_uint64(seed & 0xFFFFFFFFFFFFFFFF), out.data_ptr(),
-                            _stream(x_T.device))
+                            _dev_ptr(noise_all, torch.float32, "noise"), C.c_uint64(seed & 0xFFFFFFFFFFFFFFFF), C.c_int64(int(batch_offset)),
+                            out.data_ptr(), _stream(x_T.device))
+    check_indices(workspace)
     return out
 
 
@@ -183,6 +189,7 @@ def sample_multistep(dims: EdttsDims, packed: torch.Tensor, workspace: torch.Ten
     lib().edtts_sample_multistep(C.byref(dims), packed.data_ptr(), workspace.data_ptr(), B, T, S, _dev_ptr(sem_idx, torch.int64, "sem_idx"),
                                  _dev_ptr(sem_features, torch.float32, "sem_features"), _dev_ptr(x_T, torch.float32, "x_T"), n, ts, cf,
                                  hist.data_ptr(), None if x0_all is None else x0_all.data_ptr(), out.data_ptr(), _stream(x_T.device))
+    check_indices(workspace)
     return out, x0_all
 
 
@@ -191,6 +198,8 @@ def ddim_step(alpha_bar: torch.Tensor, x_t: torch.Tensor, t: torch.Tensor, t_pre
     if x_t.shape != eps.shape:
         raise EdttsError(f"x_t {tuple(x_t.shape)} and eps_pred {tuple(eps.shape)} differ")
     B = x_t.shape[0]
+    check_table_index(t, alpha_bar.numel(), "t")
+    check_table_index(t_prev, alpha_bar.numel(), "t_prev", lo=-alpha_bar.numel())  # negative = "before the first step"
     x_prev, x0 = torch.empty_like(x_t), torch.empty_like(x_t)
     lib().edtts_ddim_step(_dev_ptr(alpha_bar, torch.float32, "alpha_bar"), alpha_bar.numel(), _dev_ptr(x_t, torch.float32, "x_t"),
                           _dev_ptr(eps, torch.float32, "eps_pred"), _dev_ptr(t, torch.int64, "t"), _dev_ptr(t_prev, torch.int64, "t_prev"),
@@ -201,6 +210,7 @@ def ddim_step(alpha_bar: torch.Tensor, x_t: torch.Tensor, t: torch.Tensor, t_pre
 
 def ddpm_step(alphas, alpha_bar, betas, post_var, x_t, t, eps, noise) -> torch.Tensor:
     B = x_t.shape[0]
+    check_table_index(t, alpha_bar.numel(), "t")
     out = torch.empty_like(x_t)
     lib().edtts_ddpm_step(_dev_ptr(alphas, torch.float32, "alphas"), _dev_ptr(alpha_bar, torch.float32, "alpha_bar"),
                           _dev_ptr(betas, torch.float32, "betas"), _dev_ptr(post_var, torch.float32, "posterior_variance"),
@@ -220,6 +230,43 @@ def dsconv_forward(x, dw, pw, pb, gn_w, gn_b, groups: int) -> torch.Tensor:
                                _dev_ptr(pb, f, "pointwise.bias"), _dev_ptr(gn_w, f, "norm.weight"), _dev_ptr(gn_b, f, "norm.bias"),
                                B, Ci, Co, T, ks, groups, scratch.data_ptr(), y.data_ptr(), _stream(x.device))
     return y
+
+
+def randn(shape, device, seed: int = 0, stream_id: int = 0, elem_offset: int = 0, scale: float = 1.0) -> torch.Tensor:
+    """scale * N(0, 1) from the library's Philox stream (seed, stream_id) at global element offset `elem_offset`: the start
+    noise of a batch shard, identical to what one GPU would draw for the same rows (include/edtts.h: edtts_randn)."""
+    out = torch.empty(tuple(shape), dtype=torch.float32, device=device)
+    if not out.is_cuda:
+        raise EdttsError(f"randn: expected a HIP device, got {out.device} -- the MI355X sampler path has no CPU fallback")
+    lib().edtts_randn(out.data_ptr(), out.numel(), C.c_uint64(seed & 0xFFFFFFFFFFFFFFFF), C.c_uint32(stream_id & 0xFFFFFFFF),
+                      C.c_uint64(int(elem_offset)), float(scale), _stream(out.device))
+    return out
+
+
+CHECK_INDICES = os.environ.get("EDTTS_CHECK_INDICES", "0") == "1"
+
+
+def index_errors(workspace: torch.Tensor) -> int:
+    """EDTTS_IDX_* bits recorded since the last call (synchronises the current stream)."""
+    flags = C.c_int(0)
+    lib().edtts_index_errors(workspace.data_ptr(), C.byref(flags), _stream(workspace.device))
+    return flags.value
+
+
+def check_indices(workspace: torch.Tensor) -> None:
+    """Debug mode (EDTTS_CHECK_INDICES=1 or native.CHECK_INDICES = True): raise IndexError where the reference would have --
+    the kernels clamp out-of-range token / step indices instead of faulting (include/edtts.h: edtts_index_errors)."""
+    if not CHECK_INDICES or torch.cuda.is_current_stream_capturing():
+        return
+    flags = index_errors(workspace)
+    if flags:
+        what = [n for b, n in ((1, "sem_idx outside [0, codebook_size)"), (2, "step_idx outside [0, n_step_emb)")) if flags & b]
+        raise IndexError("index out of range in the decoder call: " + "; ".join(what))
+
+
+def check_table_index(t: torch.Tensor, n: int, name: str, lo: int = 0) -> None:
+    if CHECK_INDICES and not torch.cuda.is_current_stream_capturing() and bool(((t < lo) | (t >= n)).any()):
+        raise IndexError(f"{name}: index out of range [{lo}, {n})")
 
 
 def profile_enable(max_records: int) -> None:

@@ -26,8 +26,9 @@ def shard_sizes(total: int, world: int) -> List[int]:
     return [hi - lo for lo, hi in (shard_bounds(total, world, r) for r in range(world))]
 
 
-def gather_batch(local: torch.Tensor, total: int, group=None) -> torch.Tensor:
-    """All-gather per-rank shards (dim 0, sizes = shard_sizes(total, world)) into the full [total, ...] tensor."""
+def gather_batch(local: torch.Tensor, total: int, group=None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """All-gather per-rank shards (dim 0, sizes = shard_sizes(total, world)) into the full [total, ...] tensor.
+    `out` (equal shards only): a caller-owned [total, ...] buffer to gather into, reused across calls."""
     world = dist.get_world_size(group)
     sizes = shard_sizes(total, world)
     rank = dist.get_rank(group)
@@ -38,7 +39,9 @@ def gather_batch(local: torch.Tensor, total: int, group=None) -> torch.Tensor:
         # rehearsal only (e.g. several ranks sharing one GPU): gloo moves host memory, so stage through the CPU
         return gather_batch(local.cpu(), total, group).to(local.device)
     if len(set(sizes)) == 1:  # the common case: one in-place collective into the output buffer
-        out = torch.empty((total,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        shape = (total,) + tuple(local.shape[1:])
+        if out is None or tuple(out.shape) != shape or out.dtype != local.dtype or out.device != local.device:
+            out = torch.empty(shape, dtype=local.dtype, device=local.device)
         dist.all_gather_into_tensor(out, local, group=group)
         return out
     mx = max(sizes)  # ragged: pad every shard to the largest, gather, drop the padding
@@ -78,13 +81,31 @@ def generate_overlapped(local_generate: Callable, sem_local: torch.Tensor, x_loc
     return out.to(sem_local.device) if staged else out
 
 
+class _LocalRows:
+    """Rows [lo, hi) of a [B, ...] tensor that only exists shard-wise: slicing it with exactly [lo:hi] returns the shard."""
+
+    def __init__(self, rows: torch.Tensor, lo: int, hi: int, total: int):
+        self.rows, self.lo, self.hi = rows, lo, hi
+        self.shape = (total,) + tuple(rows.shape[1:])
+
+    def __getitem__(self, sl):
+        if not isinstance(sl, slice) or (sl.start, sl.stop, sl.step) != (self.lo, self.hi, None):
+            raise IndexError("only the owning rank's [lo:hi] block of the start noise exists")
+        return self.rows
+
+    def new_empty(self, shape):
+        return self.rows.new_empty(shape)
+
+
 class ShardedEdgeInference:
     """generate_mel over a process group: every rank passes the SAME global sem_idx (and optionally the same global
     x_T); each computes its contiguous block with `local_generate` and receives the full [B, 2S, n_mels] result.
 
     `local_generate(sem_idx_local, num_steps, x_T_local) -> mel_local` defaults to EdgeInference.generate_mel of the
-    wrapped object.  The start noise is drawn for the GLOBAL batch from `seed` and sliced, so the result does not depend
-    on the number of ranks (bitwise)."""
+    wrapped object.  The start noise depends only on (`seed`, global utterance index), so the result does not depend on the
+    number of ranks (bitwise): on the GPU each rank draws ITS rows from the library's counter-based Philox stream at its global
+    offset (edtts_randn -- no rank materialises the global noise); CPU tensors (host-logic tests with a stand-in sampler) draw the
+    global tensor from a torch generator and slice it."""
 
     def __init__(self, infer=None, local_generate: Optional[Callable] = None, group=None, micro_batches: int = 1):
         if infer is None and local_generate is None:
@@ -101,9 +122,19 @@ class ShardedEdgeInference:
         lo, hi = shard_bounds(B, world, rank)
         if x_T is None:
             m = n_mels if n_mels is not None else self.infer.cfg.n_mels
-            g = torch.Generator(device=sem_idx.device).manual_seed(seed)
-            x_T = torch.randn(B, 2 * S, m, device=sem_idx.device, generator=g) * temperature
+            if sem_idx.is_cuda:
+                from . import native
+                x_loc = native.randn((hi - lo, 2 * S, m), sem_idx.device, seed, 0, lo * 2 * S * m, temperature)
+                x_T = _LocalRows(x_loc, lo, hi, B)
+            else:
+                g = torch.Generator(device=sem_idx.device).manual_seed(seed)
+                x_T = torch.randn(B, 2 * S, m, device=sem_idx.device, generator=g) * temperature
         if self.micro_batches > 1 and B % world == 0 and (B // world) % self.micro_batches == 0:
             return generate_overlapped(self._local, sem_idx[lo:hi], x_T[lo:hi], num_steps, B, self.micro_batches, self.group)
-        local = self._local(sem_idx[lo:hi].contiguous(), num_steps, x_T[lo:hi].contiguous())
+        if hi == lo:
+            # fewer utterances than ranks (e.g. BASELINE config 1, B = 1): this rank has nothing to sample -- the kernels
+            # reject B < 1 -- but must still take part in the collective, with an empty shard
+            local = x_T.new_empty((0,) + tuple(x_T.shape[1:]))
+        else:
+            local = self._local(sem_idx[lo:hi].contiguous(), num_steps, x_T[lo:hi].contiguous())
         return gather_batch(local, B, self.group)

@@ -56,6 +56,7 @@ def decoder_shapes(cfg, max_pos: int = 1000, max_ctx_pos: int = 512, n_step_emb:
     """State-dict key -> shape, in the reference's registration order (models/decoder.py:17-64)."""
     H, M, R = cfg.hidden, cfg.n_mels, cfg.hidden // 2
     F = cfg.hidden * cfg.ffn_mult
+    adaln = bool(getattr(cfg, "use_adaln", True))
     s: "OrderedDict[str, Tuple[int, ...]]" = OrderedDict()
     s["token_emb.weight"] = (cfg.codebook_size, H)
     s["sem_proj.weight"] = (H, cfg.semantic_dim)
@@ -71,9 +72,12 @@ def decoder_shapes(cfg, max_pos: int = 1000, max_ctx_pos: int = 512, n_step_emb:
     s["context_pos_emb.pe"] = (max_ctx_pos, H)
     for i in range(cfg.layers):
         p = f"layers.{i}."
-        s[p + "norm1.norm.weight"] = (H,)
-        s[p + "norm1.proj.weight"] = (2 * H, H)
-        s[p + "norm1.proj.bias"] = (2 * H,)
+        if adaln:
+            s[p + "norm1.norm.weight"] = (H,)
+            s[p + "norm1.proj.weight"] = (2 * H, H)
+            s[p + "norm1.proj.bias"] = (2 * H,)
+        else:  # plain RMSNorm blocks (layers/transformer.py:101-104)
+            s[p + "norm1.weight"] = (H,)
         s[p + "attn.qkv.weight"] = (3 * H, H)
         s[p + "attn.proj.weight"] = (H, H)
         s[p + "attn.proj.bias"] = (H,)
@@ -83,9 +87,12 @@ def decoder_shapes(cfg, max_pos: int = 1000, max_ctx_pos: int = 512, n_step_emb:
         s[p + "cross_attn.kv_norm.weight"] = (R,)
         s[p + "cross_attn.kv_up_proj.weight"] = (2 * H, R)
         s[p + "cross_attn.out_proj.weight"] = (H, H)
-        s[p + "norm3.norm.weight"] = (H,)
-        s[p + "norm3.proj.weight"] = (2 * H, H)
-        s[p + "norm3.proj.bias"] = (2 * H,)
+        if adaln:
+            s[p + "norm3.norm.weight"] = (H,)
+            s[p + "norm3.proj.weight"] = (2 * H, H)
+            s[p + "norm3.proj.bias"] = (2 * H,)
+        else:  # layers/transformer.py:119-122
+            s[p + "norm3.weight"] = (H,)
         s[p + "ffn.net.0.weight"] = (2 * F, H)
         s[p + "ffn.net.0.bias"] = (2 * F,)
         s[p + "ffn.net.3.weight"] = (H, F)
@@ -108,7 +115,7 @@ def synth_state_dict(cfg, seed: int = 0, max_pos: int = 1000, max_ctx_pos: int =
             continue
         u = hash_uniform(shape, seed, stream)
         leaf = key.rsplit(".", 1)[-1]
-        if key.endswith("norm.weight") or key.endswith("norm2.weight") or key == "final_norm.weight" or key.endswith("kv_norm.weight"):
+        if key.endswith("norm.weight") or key.endswith("norm2.weight") or key.endswith("norm1.weight") or key.endswith("norm3.weight") or key == "final_norm.weight" or key.endswith("kv_norm.weight"):
             v = 1.0 + 0.1 * u                      # norm gains near 1
         elif key.endswith("emb.weight"):
             v = 0.5 * u                            # embeddings

@@ -27,13 +27,20 @@
 extern "C" {
 #endif
 
-#define EDTTS_VERSION 100 /* 0.1.0 */
+#define EDTTS_VERSION 200 /* 0.2.0 */
 
 enum {
   EDTTS_OK = 0,
   EDTTS_ERR_UNSUPPORTED = -1, /* dims have no compiled kernel instance            */
   EDTTS_ERR_ARG = -2,         /* null pointer / size out of range (IndexError/RuntimeError analogue) */
   EDTTS_ERR_HIP = -3          /* a HIP runtime call or launch failed              */
+};
+
+/* Bits of the index-error word (edtts_index_errors): an index the reference would have raised IndexError for was
+ * clamped into range by a kernel (the kernels never fault on bad indices). */
+enum {
+  EDTTS_IDX_SEM = 1, /* sem_idx outside [0, codebook_size)   (nn.Embedding, models/decoder.py:88) */
+  EDTTS_IDX_STEP = 2 /* step_idx outside [0, n_step_emb)     (models/decoder.py:79-80) */
 };
 
 /* Decoder hyper-parameters: the CFG fields read by models/decoder.py:17-64 plus table sizes. */
@@ -77,6 +84,15 @@ int edtts_pack_weights(const EdttsDims* dims, const void* const* slots, int n_sl
  * num_steps for the fused sampler).  The workspace must be ZERO-FILLED once after allocation (padding
  * lanes are read but never written) and may then be reused for any number of calls of the same shape. */
 int edtts_workspace_bytes(const EdttsDims* dims, int B, int T, int S, int cond_rows, size_t* out_bytes);
+
+/* Out-of-range indices: where the reference raises IndexError (token ids >= codebook_size, step_idx >= 16), the kernels clamp
+ * the index -- they never fault -- and OR an EDTTS_IDX_* bit into the first word of the workspace.  This call copies that word
+ * to *flags_host, clears it, and SYNCHRONISES `stream` (the one call of this library that does; not graph-capturable).  The
+ * Python host calls it after every decoder / sampler call when EDTTS_CHECK_INDICES=1 and raises IndexError, as the reference
+ * does (a deviation from the reference otherwise: a corrupted token stream yields a plausible mel, silently).
+ * (t / t_prev of edtts_ddim_step / edtts_ddpm_step are clamped into the table too; those calls have no workspace, the host
+ * checks them with a device reduction in the same debug mode.) */
+int edtts_index_errors(void* workspace, int* flags_host, void* stream);
 
 /* ---- decoder forward  (models/decoder.py:66-109, EdgeDiffusionDecoder.forward) --------------------------
  * x [B,T,n_mels], t [B] int64, step_idx [B] int64 or NULL, exactly one of sem_idx [B,S] int64 /
@@ -123,11 +139,21 @@ int edtts_generate(const EdttsDims* dims, const void* packed, void* workspace, i
  * the timesteps in the order they are visited; coef (host) float[num_steps*3] = {1/sqrt(alpha_t),
  * beta_t/sqrt(1-alpha_bar_t), [t>0]*sqrt(posterior_variance_t)} per step (schedule.py:227-237).
  * Noise: noise_all [num_steps,B,2S,n_mels] if non-NULL (parity runs inject the draws the oracle used),
- * otherwise standard normals from an in-kernel Philox4x32-10 generator keyed by (seed, step, element).
+ * otherwise standard normals from an in-kernel Philox4x32-10 generator keyed by (seed, step, GLOBAL element index), where
+ * global element = batch_offset*2S*n_mels + local element: a rank that samples rows [lo, hi) of a batch passes batch_offset = lo
+ * and draws what a single GPU would have drawn for those rows.  seed and step are by-value kernel arguments: a captured
+ * hipGraph replays the SAME noise; to advance it, re-capture or update the kernel node parameters with a new seed.
  * The workspace must have been sized with cond_rows = num_steps.  x_out receives x after the last step. */
 int edtts_sample_ddpm(const EdttsDims* dims, const void* packed, void* workspace, int B, int S,
                       const int64_t* sem_idx, const float* x_T, int num_steps, const int64_t* t_all,
-                      const float* coef_host, const float* noise_all, uint64_t seed, float* x_out, void* stream);
+                      const float* coef_host, const float* noise_all, uint64_t seed, int64_t batch_offset, float* x_out,
+                      void* stream);
+
+/* ---- start noise  (inference.py:33: torch.randn(B, T_out, n_mels) * temperature) ---------------------------------
+ * out[i] = scale * N(0,1) drawn from the Philox4x32-10 stream (seed, stream_id) at GLOBAL element index elem_offset + i, for
+ * i in [0, n): a rank that owns rows [lo, hi) of a batch passes elem_offset = lo*T*n_mels and gets exactly the values a
+ * single GPU would draw for those rows (shard-count-invariant, no global draw).  n and elem_offset multiples of 4. */
+int edtts_randn(float* out, size_t n, uint64_t seed, uint32_t stream_id, uint64_t elem_offset, float scale, void* stream);
 
 /* ---- multistep x0-solver sampler  (schedule.py:440-527, DPMSolverPP.sample with the updates of :339-438) -------
  * For step i = 0 .. num_steps-1 (t = timesteps_host[i], step_idx = i as in schedule.py:475-479):

@@ -48,7 +48,10 @@ def rms_norm(x: Tensor, weight: Tensor, eps: float = 1e-6) -> Tensor:
 
 
 def ada_rms_norm(x: Tensor, cond: Tensor, sd: SD, prefix: str) -> Tensor:
-    """layers/transformer.py:64-68 -- scale is the FIRST half of proj(cond), shift the second."""
+    """layers/transformer.py:64-68 -- scale is the FIRST half of proj(cond), shift the second.
+    With use_adaln=False the block holds a plain RMSNorm under `<prefix>weight` instead (transformer.py:101-104,142-157)."""
+    if prefix + "proj.weight" not in sd:
+        return rms_norm(x, sd[prefix + "weight"])
     mod = linear(cond, sd[prefix + "proj.weight"], sd[prefix + "proj.bias"])
     H = x.shape[-1]
     scale, shift = mod[:, :H], mod[:, H:]

@@ -30,7 +30,7 @@ def cu(t):
 
 def test_library_is_loaded():
     from edge_diffusion_tts_amd import native
-    assert native.lib().edtts_version() >= 100
+    assert native.lib().edtts_version() >= 200
     assert torch.cuda.is_available()
 
 
@@ -50,10 +50,27 @@ def test_alpha_bar_table_matches_golden(golden):
     assert torch.equal(DiffusionSchedule(1000).alpha_bar, golden("schedule_tables")["alpha_bar"])
 
 
+def _ddim_exact_fp32(alpha_bar, x, t, t_prev, eps):
+    """schedule.py:179-200 with EVERY fp32 operation correctly rounded, independent of the host's libm / vector units: each
+    operation is evaluated in fp64 on fp32 operands and rounded to fp32 once (for +, -, *, /, sqrt of fp32 values the fp64
+    result rounded to fp32 IS the IEEE fp32 result: 53 >= 2*24 + 2).  torch.sqrt on some host CPUs is not correctly rounded
+    for every input, which is why the plain fp32 oracle is only compared to 1 ulp below."""
+    f32 = lambda v: v.to(torch.float32).to(torch.float64)  # noqa: E731  (round to fp32, keep carrying fp64)
+    ab = alpha_bar[t].double()[:, None, None]
+    abp = torch.where((t_prev >= 0), alpha_bar[t_prev.clamp(min=0)].double(), torch.ones_like(t_prev, dtype=torch.float64))[:, None, None]
+    xd, ed = x.double(), eps.double()
+    s1m = f32(torch.sqrt(f32(1.0 - ab)))
+    sab = f32(torch.sqrt(ab))
+    x0 = f32(f32(xd - f32(s1m * ed)) / sab).clamp(-3.0, 3.0)
+    cdir = f32(torch.sqrt(f32(f32(1.0 - abp) - 0.0)))          # eta = 0: sigma^2 = 0
+    xp = f32(f32(f32(torch.sqrt(abp)) * x0) + f32(cdir * ed))
+    return xp.float(), x0.float()
+
+
 def test_ddim_large_vs_oracle():
-    """Full-size DDIM update against the oracle evaluated on this box's host CPU.  The committed golden vectors are
-    matched bit-exactly (test above); here 1 ulp of slack is allowed because torch.sqrt on the GPU box's host CPU is
-    not correctly rounded for every input (measured: the kernel equals the exactly-rounded value)."""
+    """Full-size DDIM update (schedule.py:157-202): BIT-EQUAL to the exactly rounded fp32 evaluation of the reference's operation
+    sequence, and within 1 ulp of the plain fp32 oracle run on this box's host CPU (whose torch.sqrt need not be correctly
+    rounded; the committed golden vectors, made in the build container, are matched bit-exactly in test_ddim_ddpm_bit_exact)."""
     gen = torch.Generator().manual_seed(1)
     B, T, M = 16, 512, 80
     x, eps = torch.randn(B, T, M, generator=gen) * 2, torch.randn(B, T, M, generator=gen)
@@ -61,9 +78,14 @@ def test_ddim_large_vs_oracle():
     tp = (t - 250).clamp(min=-1)
     sch = DiffusionSchedule(1000).to(DEV)
     xp, x0 = sch.get_ddim_step(cu(x), cu(t), cu(tp), cu(eps))
-    rxp, rx0 = O.ddim_step(O.schedule_tables(1000)["alpha_bar"], x, t, tp, eps)
+    ab = O.schedule_tables(1000)["alpha_bar"]
+    exp_xp, exp_x0 = _ddim_exact_fp32(ab, x, t, tp, eps)
+    assert torch.equal(x0.cpu(), exp_x0) and torch.equal(xp.cpu(), exp_xp)
+    rxp, rx0 = O.ddim_step(ab, x, t, tp, eps)
     torch.testing.assert_close(xp.cpu(), rxp, rtol=1e-6, atol=1e-6)   # SURVEY.md section 8d (ii); values are O(1)
     torch.testing.assert_close(x0.cpu(), rx0, rtol=1e-6, atol=1e-6)
+    n_diff = int((x0.cpu() != rx0).sum() + (xp.cpu() != rxp).sum())
+    print(f"ddim full size: kernel == exactly-rounded fp32 (bitwise); host fp32 oracle differs from it in {n_diff} of {2 * x.numel()} values")
     assert float(x0.abs().max()) <= 3.0
 
 
@@ -138,19 +160,28 @@ def test_cpu_tensors_fail_loudly():
         DiffusionSchedule(1000).get_ddim_step(torch.zeros(1, 4, 80), torch.zeros(1, dtype=torch.long), torch.zeros(1, dtype=torch.long), torch.zeros(1, 4, 80))
 
 
-def e2e_check(ours, ref, what):
-    """End-to-end criterion (DESIGN.md "Parity protocol").  At t=999 x0 = (x - s*eps)/1.558e-5 amplifies any
-    eps rounding difference 64171x before the clamp, and the few unclamped elements then perturb their neighbours through
-    the later steps' attention, so no fp32 implementation with a different summation order meets 1e-3 on EVERY element
-    (the reference's own fp32 vs fp64 run differs by up to 6.9e-3 on this input).  Required: >= 99.7 % of the elements
-    within 1e-3, none beyond 0.1, and the median error at rounding level."""
-    err = (ours.double() - ref.double()).abs().flatten()
-    frac_bad = float((err > E2E_TOL).double().mean())
-    print(f"{what}: max {float(err.max()):.2e} median {float(err.median()):.2e} p99.9 {float(err.quantile(0.999)):.2e} "
-          f"frac>1e-3 {frac_bad:.2e}")
-    assert frac_bad <= 3e-3, (what, frac_bad)
-    assert float(err.max()) < 0.1, (what, float(err.max()))
-    assert float(err.median()) < 2e-5, (what, float(err.median()))
+def amplification_band(x_T, eps0, k=4.0):
+    """the elements whose FIRST-step x0 = (x_T - sqrt(1-ab) eps0) / sqrt(ab) is not (safely) clamped,
+    |x_T - sqrt(1-ab) eps0| < 4.7e-5 * k with k = 4, i.e. |x0| < 3k before the clamp: there an eps rounding difference is
+    amplified 1/sqrt(alpha_bar[999]) = 64171x."""
+    ab = O.schedule_tables(1000)["alpha_bar"][999].double()
+    return (x_T.double() - torch.sqrt(1 - ab) * eps0.double()).abs() < 3.0 * torch.sqrt(ab) * k
+
+
+def e2e_check(ours, ref, band, what, ref32=None, fp64=None, tol=E2E_TOL):
+    """End-to-end criterion exactly as SURVEY.md section 8d (iii) states it: max-abs <= 1e-3 over the elements OUTSIDE the
+    t=999 unclamped band; the in-band count and maximum are reported next to the reference's own fp32-vs-fp64 error on the
+    same elements (ref32 / fp64 given)."""
+    err = (ours.double() - ref.double()).abs()
+    out_band, in_band = err[~band], err[band]
+    msg = (f"{what}: outside the band max {float(out_band.max()):.2e} (n>1e-3: {int((out_band > E2E_TOL).sum())} of {out_band.numel()}), "
+           f"median {float(err.median()):.2e}; in band: {in_band.numel()} elements, max {float(in_band.max()) if in_band.numel() else 0.0:.2e}")
+    if ref32 is not None and fp64 is not None:
+        r = (ref32.double() - fp64.double()).abs()
+        msg += (f" | reference fp32 vs fp64 on the same split: outside max {float(r[~band].max()):.2e}, "
+                f"in band max {float(r[band].max()) if in_band.numel() else 0.0:.2e}")
+    print(msg)
+    assert float(out_band.max()) <= tol, msg
 
 
 def test_generate_cfg1(golden):
@@ -162,12 +193,15 @@ def test_generate_cfg1(golden):
     infer = EdgeInference(cfg, sch, torch.nn.Identity(), dec)
     out = infer.generate_mel(cu(g["sem_idx"]), 4, x_T=cu(g["x_T"])).cpu()
     assert out.shape == g["out"].shape and float(out.abs().max()) <= 3.0
-    e2e_check(out, g["out"], "generate_mel cfg1 vs reference fp32")
-    # the same comparison against the fp64 arbiter, next to the reference's own fp32-vs-fp64 distance
+    band = amplification_band(g["x_T"], g["eps0"])
     sd64 = O.cast_sd(synth_state_dict(cfg, 0), torch.float64)
     out64 = O.generate_mel(sd64, O.schedule_tables(1000, torch.float64)["alpha_bar"], g["sem_idx"], g["x_T"].double(), 4)
-    e2e_check(out, out64, "generate_mel cfg1 vs fp64 arbiter")
-    e2e_check(g["out"], out64, "reference fp32 vs fp64 arbiter (context)")
+    e2e_check(out, g["out"], band, "generate_mel cfg1 vs reference fp32", ref32=g["out"], fp64=out64)
+    # Context, not the contract: against the fp64 arbiter BOTH fp32 implementations carry their own in-band errors (reference:
+    # 6.9e-3), which leak to a few neighbours through the later steps' attention; ours must stay within twice the reference's own
+    # out-of-band distance from fp64.
+    ref_out_band = float((g["out"].double() - out64).abs()[~band].max())
+    e2e_check(out, out64, band, "generate_mel cfg1 vs fp64 arbiter", ref32=g["out"], fp64=out64, tol=max(E2E_TOL, 2 * ref_out_band))
     # teacher-forced: every step fed the reference's own x_t matches to the single-forward tolerance, and the DDIM
     # update applied to the reference's eps is bit-exact
     for i, t in enumerate([999, 749, 499, 249]):
@@ -178,9 +212,12 @@ def test_generate_cfg1(golden):
         xp, x0 = sch.get_ddim_step(cu(xin), tt, torch.full((1,), max(t - 250, 0), device=DEV), cu(g[f"eps{i}"]))
         assert torch.equal(xp.cpu(), g[f"x_prev{i}"]) and torch.equal(x0.cpu(), g[f"x0_{i}"]), i
     # other step counts
+    sd = synth_state_dict(cfg, 0)
     for n in (1, 2, 16):
         o = infer.generate_mel(cu(g["small_sem_idx"]), n, x_T=cu(g["small_x_T"])).cpu()
-        e2e_check(o, g[f"small_out_n{n}"], f"generate_mel {n}-step vs reference fp32")
+        tr = []
+        O.generate_mel(sd, O.schedule_tables(1000)["alpha_bar"], g["small_sem_idx"], g["small_x_T"], n, trace=tr)
+        e2e_check(o, g[f"small_out_n{n}"], amplification_band(g["small_x_T"], tr[0]["eps"]), f"generate_mel {n}-step vs reference fp32")
 
 
 def test_generate_default_init_exact(golden):
@@ -250,8 +287,9 @@ def test_full_size_config2_properties():
     assert torch.equal(small, big[idx])
     # and one of them against the CPU oracle (outside the amplification band)
     sd = synth_state_dict(cfg, 0)
-    ref = O.generate_mel(sd, O.schedule_tables(1000)["alpha_bar"], sem[131:132].cpu(), x[131:132].cpu(), 4)
-    e2e_check(big[131:132].cpu(), ref, "config-2 utterance 131 vs oracle")
+    tr = []
+    ref = O.generate_mel(sd, O.schedule_tables(1000)["alpha_bar"], sem[131:132].cpu(), x[131:132].cpu(), 4, trace=tr)
+    e2e_check(big[131:132].cpu(), ref, amplification_band(x[131:132].cpu(), tr[0]["eps"]), "config-2 utterance 131 vs oracle")
 
 
 def test_dsconv(golden):
@@ -552,3 +590,138 @@ def test_no_cross_block_hazard_when_utterances_straddle_block_rounds():
     for u in (0, 5, 13, 21, 29, 37, 45, 53, 61, 63):
         solo = dec(x[u:u + 1].contiguous(), t[:1], sem[u:u + 1].contiguous(), si[:1])
         assert torch.equal(solo[0], big[u]), u
+
+
+def test_forward_without_adaln(golden):
+    """CFG(use_adaln=False): plain RMSNorm blocks (layers/transformer.py:101-104,119-122,142-157) against the reference's output."""
+    g = golden("forward_noadaln")
+    cfg = CFG(use_adaln=False, device=DEV)
+    dec = make_decoder(cfg, 4)
+    e = dec(cu(g["x_t"]), cu(g["t"]), cu(g["sem_idx"]), cu(g["step_idx"])).cpu()
+    assert max_abs(e, g["eps"]) < FWD_TOL
+    # and it is a different network from the AdaLN one with the same shared weights (the branch is really taken)
+    assert float(g["eps"].abs().max()) > 0.1
+
+
+def test_checkpoint_interop_on_device(golden, tmp_path):
+    """SURVEY.md section 8f-2 on the HIP path: a reference-style checkpoint (train.py:291-297) whose decoder keys carry the
+    `_orig_mod.` prefix torch.compile leaves (train.py:84-86,195), with the FSQ-sized 2304-row token embedding (train_v2.py:246)
+    while the stored cfg still says codebook_size=512 -> from_checkpoint -> eps equal to the reference's output, ids up to 2303."""
+    g = golden("forward_fsq")
+    cfg = CFG(codebook_size=2304, device="cpu")
+    sd = synth_state_dict(cfg, 6)
+    stored_cfg = CFG(device="cpu").to_dict()                   # codebook_size = 512 in the stored config
+    ck = {"decoder": {"_orig_mod." + k: v.clone() for k, v in sd.items()}, "cfg": stored_cfg, "encoder_proj": {}, "encoder_vq": {}}
+    path = tmp_path / "edge_model_final.pt"
+    torch.save(ck, path)
+    dec = EdgeDiffusionDecoder.from_checkpoint(str(path), device=DEV)
+    assert dec.cfg.codebook_size == 2304 and int(g["sem_idx"].max()) == 2303
+    e = dec(cu(g["x_t"]), cu(g["t"]), cu(g["sem_idx"]), cu(g["step_idx"])).cpu()
+    assert max_abs(e, g["eps"]) < FWD_TOL
+    assert max_abs(e, O.decoder_forward(sd, g["x_t"], g["t"], g["sem_idx"], g["step_idx"])) < FWD_TOL
+    # the sampler runs on the loaded decoder too
+    infer = EdgeInference(dec.cfg, DiffusionSchedule(1000).to(DEV), torch.nn.Identity(), dec)
+    out = infer.generate_mel(cu(g["sem_idx"]), 2, x_T=cu(g["x_t"]))
+    assert out.shape == g["x_t"].shape and bool(torch.isfinite(out).all())
+
+
+class _StubEncoder(torch.nn.Module):
+    """Stands in for SemanticEncoder (HuBERT + quantiser, models/encoder.py -- a network fetch, out of scope): returns the
+    reference's 5-tuple (z_q, indices, commit_loss, perplexity, features) with deterministic indices derived from the waveform."""
+
+    def __init__(self, codebook_size, hop=320):
+        super().__init__()
+        self.codebook_size, self.hop, self.calls = codebook_size, hop, 0
+
+    def forward(self, wav):
+        self.calls += 1
+        S = wav.shape[1] // self.hop
+        frames = wav[:, :S * self.hop].reshape(wav.shape[0], S, self.hop)
+        idx = (frames.abs().mean(-1) * 7919.0).long() % self.codebook_size
+        return None, idx, torch.zeros(()), torch.zeros(()), None
+
+
+def test_generate_from_audio_with_stub_encoder():
+    """EdgeInference.generate_from_audio (inference.py:55-62): wav -> encoder(wav)[1] -> generate_mel; 1-D wav is unsqueezed."""
+    cfg = CFG(device=DEV)
+    dec = make_decoder(cfg, 0)
+    enc = _StubEncoder(cfg.codebook_size).to(DEV)
+    infer = EdgeInference(cfg, DiffusionSchedule(cfg.diff_steps).to(DEV), enc, dec)
+    gen = torch.Generator().manual_seed(12)
+    wav = torch.randn(2, 320 * 20, generator=gen)
+    torch.manual_seed(99)
+    out = infer.generate_from_audio(wav, num_steps=4)
+    assert out.shape == (2, 40, cfg.n_mels) and enc.calls == 1 and float(out.abs().max()) <= 3.0
+    # same thing by hand: the encoder's indices through generate_mel with the same device RNG state
+    _, idx, _, _, _ = enc(wav.to(DEV))
+    torch.manual_seed(99)
+    assert torch.equal(out, infer.generate_mel(idx, 4))
+    one = infer.generate_from_audio(wav[0], num_steps=1)     # 1-D waveform
+    assert one.shape == (1, 40, cfg.n_mels)
+
+
+def test_out_of_range_indices_are_flagged():
+    """Where the reference raises IndexError (token id >= codebook_size, step_idx >= 16) the kernels clamp and record it; the
+    debug mode EDTTS_CHECK_INDICES=1 turns the record into an IndexError (include/edtts.h: edtts_index_errors)."""
+    from edge_diffusion_tts_amd import native
+    cfg = CFG(device=DEV)
+    dec = make_decoder(cfg, 0)
+    x = torch.zeros(1, 32, 80, device=DEV)
+    t = torch.tensor([5], device=DEV)
+    good = torch.zeros(1, 16, dtype=torch.long, device=DEV)
+    dec(x, t, good, torch.tensor([3], device=DEV))
+    ws = dec.workspace(1, 32, 16, 1, x.device)
+    assert native.index_errors(ws) == 0
+    bad = good.clone()
+    bad[0, 3] = 512
+    dec(x, t, bad, torch.tensor([16], device=DEV))
+    assert native.index_errors(ws) == 3 and native.index_errors(ws) == 0   # both bits; reading clears
+    old = native.CHECK_INDICES
+    native.CHECK_INDICES = True
+    try:
+        with pytest.raises(IndexError, match="sem_idx"):
+            dec(x, t, bad, None)
+        with pytest.raises(IndexError, match="step_idx"):
+            dec(x, t, good, torch.tensor([-1], device=DEV))
+        dec(x, t, good, torch.tensor([15], device=DEV))
+        with pytest.raises(IndexError):
+            DiffusionSchedule(1000).to(DEV).get_ddim_step(x, torch.tensor([1000], device=DEV), torch.tensor([0], device=DEV), x)
+    finally:
+        native.CHECK_INDICES = old
+
+
+def test_library_noise_is_shard_invariant():
+    """edtts_randn / the in-kernel DDPM noise are keyed by the GLOBAL element index: a rank that owns rows [lo, hi) draws exactly
+    the values a single GPU draws for those rows (no rank has to materialise the global noise)."""
+    from edge_diffusion_tts_amd import native
+    full = native.randn((6, 64, 80), DEV, seed=5)
+    part = native.randn((2, 64, 80), DEV, seed=5, elem_offset=3 * 64 * 80)
+    assert torch.equal(part, full[3:5])
+    z = native.randn((64, 512, 80), DEV, seed=1).flatten().double()
+    assert abs(float(z.mean())) < 3e-3 and abs(float(z.std()) - 1.0) < 3e-3 and abs(float((z ** 4).mean()) - 3.0) < 0.03
+    assert not torch.equal(native.randn((2, 64, 80), DEV, seed=6), full[:2])
+    assert torch.equal(native.randn((2, 64, 80), DEV, seed=5, scale=0.5), full[:2] * 0.5)
+    cfg, infer, sem, x_T, _ = _ddpm_setup(20, 4, 32, 5)
+    whole = infer.sample_ddpm(cu(sem), 3, x_T=cu(x_T), seed=7)
+    shard = infer.sample_ddpm(cu(sem[2:]), 3, x_T=cu(x_T[2:]), seed=7, batch_offset=2)
+    assert torch.equal(shard, whole[2:])
+    # generate_mel(seed=...) draws its start noise the same way
+    a = infer.generate_mel(cu(sem), 4, seed=3)
+    b = infer.generate_mel(cu(sem[1:3]), 4, seed=3, batch_offset=1)
+    assert torch.equal(b, a[1:3])
+
+
+def test_config5_full_size_graph():
+    """BASELINE config 5 at full size: 1000-step DDPM sampler, B=64, T=512, captured as ONE hipGraph (5 launches per step) and
+    replayed; the replay equals the eager run bitwise and stays finite."""
+    cfg, infer, sem, x_T, _ = _ddpm_setup(1000, 64, 256, 17)
+    sem_s, x_s = cu(sem), cu(x_T)
+    eager = infer.sample_ddpm(sem_s, None, x_T=x_s, seed=2)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = infer.sample_ddpm(sem_s, None, x_T=x_s, seed=2)
+    g.replay()
+    torch.cuda.synchronize()
+    assert out.shape == (64, 512, 80) and bool(torch.isfinite(out).all())
+    assert torch.equal(out, eager)

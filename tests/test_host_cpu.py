@@ -98,7 +98,7 @@ def test_library_exports_every_declared_symbol():
     for sym in declared:
         assert hasattr(L, sym), sym
     lib = native.lib()
-    assert lib.edtts_version() == 100
+    assert lib.edtts_version() == 200
 
 
 def test_slot_names_cover_the_state_dict():
@@ -169,3 +169,19 @@ def test_checkpoint_interop(tmp_path):
     # bare state-dict, strict mismatch still raises
     with pytest.raises(RuntimeError):
         EdgeDiffusionDecoder(cfg).load_state_dict({k: v for k, v in sd.items() if "ffn" not in k})
+
+
+def test_decoder_without_adaln_uses_plain_rmsnorm_keys():
+    """CFG(use_adaln=False): the reference builds RMSNorm for norm1 / norm3 (layers/transformer.py:101-104,119-122); the state-dict
+    keys follow, and the kernels' AdaLN slots are fed the gain plus an all-zero modulation projection."""
+    cfg = CFG(use_adaln=False, device="cpu")
+    dec = EdgeDiffusionDecoder(cfg)
+    keys = set(dec.state_dict())
+    assert "layers.0.norm1.weight" in keys and "layers.3.norm3.weight" in keys
+    assert not any(".norm1.proj." in k or ".norm3.norm." in k for k in keys)
+    res = dec.load_state_dict(synth_state_dict(cfg, 4))
+    assert not res.missing_keys and not res.unexpected_keys
+    slots = dec._state_tensors()
+    assert set(native.slot_names(cfg.layers)) <= set(slots)
+    assert float(slots["layers.1.norm3.proj.weight"].abs().max()) == 0.0 and slots["layers.1.norm3.proj.bias"].shape == (320,)
+    assert torch.equal(slots["layers.2.norm1.norm.weight"], dec.state_dict()["layers.2.norm1.weight"])

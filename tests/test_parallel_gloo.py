@@ -25,7 +25,10 @@ def test_shard_bounds_partition():
 
 
 def _fake_local_generate(sem, num_steps, x):
-    # deterministic per-utterance function (depends only on that utterance's tokens and noise, like the real sampler)
+    # deterministic per-utterance function (depends only on that utterance's tokens and noise, like the real sampler);
+    # like the real path (edtts_workspace_bytes rejects B < 1) it refuses an empty shard
+    if sem.shape[0] == 0:
+        raise RuntimeError("empty shard handed to the local sampler")
     return x * (1.0 + num_steps) + sem.float().mean(dim=1)[:, None, None]
 
 
@@ -63,7 +66,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("world,total", [(2, 8), (2, 7), (3, 10), (2, 16)])
+@pytest.mark.parametrize("world,total", [(2, 8), (2, 7), (3, 10), (2, 16), (3, 2), (2, 1)])
 def test_sharded_generate_gloo(world, total):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
