@@ -1,0 +1,561 @@
+// edtts_bf16.h -- bf16 instance of the decoder kernels (BASELINE config 3: hidden=256, heads=8, head_dim=32).
+// Included by edtts_kernels.hip after KArgs / tail_apply / wave_tile are defined.
+//
+// Arithmetic: every contraction runs on v_mfma_f32_16x16x32_bf16 (bf16 operands, fp32 accumulate); the residual stream h, all
+// norms, the softmax (max, exp2, sums) and the sampler update stay fp32.  Weights are rounded to bf16 once (edtts_pack_weights),
+// activations are rounded to bf16 where they enter an MFMA (normalised tiles, q / k / v, probabilities, attention outputs, SwiGLU
+// outputs) -- the reference's own AMP precedent (utils/speed_utils.py:70, train_v2.py:290) rounds the same tensors.
+//
+// Data model ("frame on the lane", as in the fp32 kernels):
+//   a wave owns 32 frames = two 16-frame tiles ft; C/D of the MFMA: lane (fq = lane & 15, g = lane >> 4) holds
+//   out[feature 16 nt + 4 g + r][frame fq], r = 0..3.  The B operand of the 16x16x32 MFMA wants, per lane, 8 bf16 = the k's
+//   {8 g + j}.  MFMA contraction order is free, so the 32 features of a k-tile are assigned to the (g, j) slots as
+//       slot(g, j) = 4 g + j            (j < 4)      <- C/D registers of n-tile 2 kt
+//                    16 + 4 g + (j - 4) (j >= 4)     <- C/D registers of n-tile 2 kt + 1
+//   and the weights are packed with the same assignment: the C/D registers of two consecutive n-tiles, converted pairwise with
+//   v_cvt_pk_bf16_f32, ARE the B operand of the next GEMM's k-tile.  Nothing leaves registers inside a layer except q / k / v^T
+//   (needed by other waves) and the layer-boundary residual.
+//   Memory images follow from that: q, k and the cross K cache are row-major [frame][H] bf16 with the 32 features of a head stored
+//   in slot order (one 16-byte load per lane is an MFMA operand; q.k is order-agnostic as long as both use the same order);
+//   v^T is [H][frames] bf16 with the 32 keys of a chunk stored in slot order (position 8 g' + 4 t + r <-> key 16 t + 4 g' + r), which
+//   is what a lane of the SWAPPED product (activations as A, weights as B: C/D = [frame][feature]) holds -- one 16-byte store.
+#pragma once
+
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+typedef float f2v __attribute__((ext_vector_type(2)));
+
+#define EDTTS_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+
+namespace edtts16 {
+using namespace edtts;
+
+template <int H_, int HEADS_, int MEL_>
+struct Cfg16 {
+  static constexpr int H = H_, HEADS = HEADS_, MEL = MEL_, NF = 2;
+  static constexpr int WF = 32;                 // frames per wave
+  static constexpr int DH = H / HEADS;          // head dim: one k-tile
+  static constexpr int HT = H / 16;             // n-tiles of the hidden dim
+  static constexpr int KT = H / 32;             // k-tiles of the hidden dim (= heads)
+  static constexpr int MT = MEL / 16;           // n-tiles of the mel dim
+  static constexpr int MKT = (MEL + 31) / 32;   // k-tiles of the mel dim (zero padded)
+  static constexpr int MTP = (MT + 1) / 2;      // n-tile PAIRS of the mel dim (the last one may be half empty)
+  static constexpr int R = H / 2;
+  static constexpr int VR = H;                  // rows of a v^T buffer
+  static constexpr int RN = HT < 16 ? HT : 16;  // weight ring: fragments in flight per wave
+  static constexpr int WAVES = 4, THREADS = 64 * WAVES;
+  static_assert(DH == 32, "the bf16 instance is built for head_dim 32 (one MFMA k-tile per head)");
+  static_assert(H % 32 == 0 && MEL % 16 == 0 && HT % RN == 0 && (2 * KT) % RN == 0, "dims vs ring");
+};
+
+EDTTS_DEV bf8 as_bf8(f4 v) { return __builtin_bit_cast(bf8, v); }
+EDTTS_DEV f4 as_f4(bf8 v) { return __builtin_bit_cast(f4, v); }
+// C/D registers of two consecutive n-tiles -> the 8 bf16 of this lane's k-slots (v_cvt_pk_bf16_f32, round to nearest even)
+EDTTS_DEV bf8 pack8(f4 a, f4 b) {
+  const bf2 p0 = __builtin_convertvector(f2v{a[0], a[1]}, bf2), p1 = __builtin_convertvector(f2v{a[2], a[3]}, bf2);
+  const bf2 p2 = __builtin_convertvector(f2v{b[0], b[1]}, bf2), p3 = __builtin_convertvector(f2v{b[2], b[3]}, bf2);
+  return bf8{p0[0], p0[1], p1[0], p1[1], p2[0], p2[1], p3[0], p3[1]};
+}
+EDTTS_DEV bf8 ldg_bf8(const __bf16* base, unsigned byte_off) {
+  return *reinterpret_cast<const bf8*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+
+template <class C> using Ring16 = FragRing<C::RN>;
+
+// two n-tiles at once from a stream that interleaves their fragments per k-tile ([kt][tile a | tile b]).
+// SWAP: activations as the A operand, weights as B -> C/D = [frame][feature] (used for v^T).
+template <int KT, bool SWAP, int RN>
+EDTTS_DEV void gemm16_pair(FragRing<RN>& ring, const bf8 (&in)[KT][2], f4 (&a)[2], f4 (&b)[2]) {
+  static_assert((2 * KT) % RN == 0, "phase length must be a multiple of the ring size");
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt) {
+    const bf8 fa = as_bf8(ring.at(2 * kt)), fb = as_bf8(ring.at(2 * kt + 1));
+#pragma unroll
+    for (int ft = 0; ft < 2; ++ft) {
+      a[ft] = SWAP ? EDTTS_MFMA16(in[kt][ft], fa, a[ft]) : EDTTS_MFMA16(fa, in[kt][ft], a[ft]);
+      b[ft] = SWAP ? EDTTS_MFMA16(in[kt][ft], fb, b[ft]) : EDTTS_MFMA16(fb, in[kt][ft], b[ft]);
+    }
+    ring.template refill_after<2 * KT>(2 * kt);
+    ring.template refill_after<2 * KT>(2 * kt + 1);
+  }
+  ring.advance(2 * KT);
+}
+// acc[nt] += frag(nt) * in  for one k-tile of a k-major packed matrix (NT fragments)
+template <int NT, int RN>
+EDTTS_DEV void ktile16(FragRing<RN>& ring, const bf8 (&in)[2], f4 (&acc)[NT][2]) {
+  static_assert(NT % RN == 0, "phase length must be a multiple of the ring size");
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const bf8 fa = as_bf8(ring.at(nt));
+    acc[nt][0] = EDTTS_MFMA16(fa, in[0], acc[nt][0]);
+    acc[nt][1] = EDTTS_MFMA16(fa, in[1], acc[nt][1]);
+    ring.template refill_after<NT>(nt);
+  }
+  ring.advance(NT);
+}
+
+// RMSNorm (+ optional AdaLN modulation) of the residual tile, straight into packed bf16 B operands
+template <class C>
+EDTTS_DEV void rms_norm_pack(const f4 (&x)[C::HT][2], const float* __restrict__ w, const float* __restrict__ mod, int g,
+                             bf8 (&y)[C::KT][2]) {
+  float rs[2];
+#pragma unroll
+  for (int ft = 0; ft < 2; ++ft) {
+    float ss = 0.f;
+#pragma unroll
+    for (int t = 0; t < C::HT; ++t) ss += hsum(x[t][ft] * x[t][ft]);
+    rs[ft] = rsqrtf(group_sum(ss) * (1.0f / C::H) + 1e-6f);
+  }
+#pragma unroll
+  for (int kt = 0; kt < C::KT; ++kt) {
+    f4 v[2][2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int t = 2 * kt + u;
+      const f4 wv = ldg4(w + 16 * t + 4 * g);
+      f4 sc = splat(1.f), sh = splat(0.f);
+      if (mod != nullptr) {
+        sc = ldg4(mod + 16 * t + 4 * g);
+        sh = ldg4(mod + C::H + 16 * t + 4 * g);
+      }
+#pragma unroll
+      for (int ft = 0; ft < 2; ++ft) {
+        f4 a = x[t][ft] * rs[ft] * wv;
+        if (mod != nullptr) a = a * sc + sh;
+        v[u][ft] = a;
+      }
+    }
+    y[kt][0] = pack8(v[0][0], v[1][0]);
+    y[kt][1] = pack8(v[0][1], v[1][1]);
+  }
+}
+template <class C>
+EDTTS_DEV void layer_norm_pack(const f4 (&x)[C::HT][2], const float* __restrict__ w, const float* __restrict__ b, int g,
+                               bf8 (&y)[C::KT][2]) {
+  float mu[2], rs[2];
+#pragma unroll
+  for (int ft = 0; ft < 2; ++ft) {
+    float s = 0.f;
+#pragma unroll
+    for (int t = 0; t < C::HT; ++t) s += hsum(x[t][ft]);
+    mu[ft] = group_sum(s) * (1.0f / C::H);
+    float v = 0.f;
+#pragma unroll
+    for (int t = 0; t < C::HT; ++t) {
+      const f4 d = x[t][ft] - mu[ft];
+      v += hsum(d * d);
+    }
+    rs[ft] = rsqrtf(group_sum(v) * (1.0f / C::H) + 1e-5f);
+  }
+#pragma unroll
+  for (int kt = 0; kt < C::KT; ++kt) {
+    f4 v[2][2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int t = 2 * kt + u;
+      const f4 wv = ldg4(w + 16 * t + 4 * g), bv = ldg4(b + 16 * t + 4 * g);
+#pragma unroll
+      for (int ft = 0; ft < 2; ++ft) v[u][ft] = (x[t][ft] - mu[ft]) * rs[ft] * wv + bv;
+    }
+    y[kt][0] = pack8(v[0][0], v[1][0]);
+    y[kt][1] = pack8(v[0][1], v[1][1]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Multi-head attention for one wave's 32 query frames, fused with the output projection (delta += W_o . concat_heads(...)).
+// One head = one MFMA k-tile: per 32-key chunk  S^T = K Q^T (4 MFMAs: 2 key tiles x 2 query tiles), online softmax in fp32 with a
+// deferred running maximum (same scheme as the fp32 kernel: the reference point rides in as the accumulator input of the score
+// MFMAs and only moves when a chunk exceeds it by 2^32), P -> bf16, O^T += V^T P^T (4 MFMAs).
+//   SELF : keys are frames of the same utterance, band |i-j| <= window (layers/attention.py:27-30,108-112)
+//   !SELF: keys are the S context tokens, no mask (layers/mla.py:158-179)
+// qf(hd, ft): this lane's q operand (8 bf16) of head hd, query tile ft.
+// ---------------------------------------------------------------------------------------------------------
+template <class C, bool SELF, class QF>
+EDTTS_DEV void attention16(QF&& qf, const __bf16* __restrict__ Kb, const __bf16* __restrict__ VTb, int ldv, int nkeys,
+                           int window, int m0, int lane, Ring16<C>& ring, f4 (&delta)[C::HT][2]) {
+  constexpr int H = C::H, DH = C::DH;
+  const int fq = lane & 15, g = lane >> 4;
+  const float NEG_INF = -__builtin_inff();
+  // chunk geometry (one half: NF = 2), as in edtts_device.h attention_fused
+  int kt_lo, kt_hi;
+  if (SELF && window >= 0) {
+    const int lo = m0 - window;
+    kt_lo = ((lo > 0 ? lo : 0) >> 4) & ~1;
+    const int hi = m0 + 31 + window;
+    const int last = hi < nkeys - 1 ? hi : nkeys - 1;
+    kt_hi = (last >> 4) + 1;
+  } else {
+    kt_lo = 0;
+    kt_hi = (nkeys + 15) >> 4;
+  }
+  const int nchunk = (kt_hi - kt_lo + 1) / 2;
+  const bool off_grid = SELF && window >= 0 && (m0 - window > (kt_lo << 4));
+  int cdiag = off_grid ? ((m0 >> 4) - kt_lo) / 2 : 0;
+  if (cdiag >= nchunk) cdiag = nchunk - 1;
+  const int klim = (kt_hi << 4) < nkeys ? (kt_hi << 4) : nkeys;
+  int lo_d[2], span[2];
+#pragma unroll
+  for (int ft = 0; ft < 2; ++ft) {
+    const int qi = m0 + 16 * ft + fq;
+    int lo = -(1 << 28), hi = klim - 1 - qi;
+    if (SELF && window >= 0) {
+      lo = -window;
+      hi = hi < window ? hi : window;
+    }
+    lo_d[ft] = lo;
+    span[ft] = hi - lo;
+  }
+  const unsigned koff = (unsigned)(fq * H + 8 * g) * 2u;    // K row of key fq, this lane's 8 k-slots
+  const unsigned voff = (unsigned)(fq * ldv + 8 * g) * 2u;  // V^T row of feature fq, this lane's 8 key slots of the chunk
+  auto clampc = [&](int c) { return c < nchunk ? c : nchunk - 1; };
+  auto load_k = [&](int hd, int c, bf8 (&ka)[2]) {
+    c = clampc(c);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      int kt = kt_lo + 2 * c + t;
+      kt = kt < kt_hi ? kt : kt_hi - 1;
+      ka[t] = ldg_bf8(Kb + (size_t)(kt << 4) * H + hd * DH, koff);
+    }
+  };
+  auto load_v = [&](int hd, int c, bf8 (&va)[2]) {
+    c = clampc(c);
+    const int k0 = (kt_lo + 2 * c) << 4;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) va[dt] = ldg_bf8(VTb + (size_t)(hd * DH + 16 * dt) * ldv + k0, voff);
+  };
+  auto chunk_is_interior = [&](int c) {
+    c = clampc(c);
+    const int k0 = (kt_lo + 2 * c) << 4, k1 = k0 + 31;
+    bool full = k1 < klim && (kt_lo + 2 * (c + 1)) <= kt_hi;
+    if (SELF && window >= 0) full = full && (k1 - m0 <= window) && (k0 - (m0 + 31) >= -window);
+    return full;
+  };
+  auto mask_init = [&](int c, f4 (&S)[2][2], const float (&vis)[2]) {
+    c = clampc(c);
+    const int k0 = (kt_lo + 2 * c) << 4;
+#pragma unroll
+    for (int ft = 0; ft < 2; ++ft) {
+      const int d0 = k0 + 4 * g - (m0 + 16 * ft + fq) - lo_d[ft];
+      const unsigned sp = span[ft] >= 0 ? (unsigned)span[ft] : 0u;
+      const int bias = span[ft] >= 0 ? 0 : (1 << 30);
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) S[t][ft][r] = (unsigned)(d0 + bias + 16 * t + r) <= sp ? vis[ft] : NEG_INF;
+    }
+  };
+
+  bf8 KA[2], VA[2], q[2];
+  auto prefetch = [&](int hd) {
+    q[0] = qf(hd, 0);
+    q[1] = qf(hd, 1);
+    load_k(hd, cdiag, KA);
+    load_v(hd, cdiag, VA);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  prefetch(0);
+  for (int hd = 0; hd < C::HEADS; ++hd) {
+    f4 O[2][2] = {{splat(0.f), splat(0.f)}, {splat(0.f), splat(0.f)}};
+    f4 lvec[2] = {splat(0.f), splat(0.f)};
+    f4 NM[2] = {splat(0.f), splat(0.f)};
+    float nm[2] = {0.f, 0.f};
+    auto step = [&](bool first, int c, int cnext) {
+      f4 S[2][2];
+      if (chunk_is_interior(c)) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int ft = 0; ft < 2; ++ft) S[t][ft] = NM[ft];  // first step: NM = 0
+      } else {
+        mask_init(c, S, nm);  // first step: nm = 0
+      }
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int ft = 0; ft < 2; ++ft) S[t][ft] = EDTTS_MFMA16(KA[t], q[ft], S[t][ft]);
+      __builtin_amdgcn_sched_barrier(0);
+      load_k(hd, cnext, KA);
+      __builtin_amdgcn_sched_barrier(0);
+      f4 P[2][2], ps[2];
+      auto lane_max = [&](int ft) {
+        f4 mv = S[0][ft];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mv[r] = fmaxf(mv[r], S[1][ft][r]);
+        return hmax(mv);
+      };
+      auto exp_and_sum = [&](int ft, float m) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) P[t][ft][r] = fast_exp2(S[t][ft][r] - m);
+        ps[ft] = P[0][ft] + P[1][ft];
+      };
+      if (first) {
+#pragma unroll
+        for (int ft = 0; ft < 2; ++ft) {
+          const float gm = group_max(lane_max(ft));
+          const float m = gm > -1e30f ? gm : 0.f;
+          nm[ft] = -m;
+          NM[ft] = splat(-m);
+          exp_and_sum(ft, m);
+        }
+      } else {
+        exp_and_sum(0, 0.f);
+        exp_and_sum(1, 0.f);
+        const float lim = 4294967296.f;  // 2^32 (kDefer)
+        if (__any(!(hsum(ps[0]) <= lim) || !(hsum(ps[1]) <= lim))) {
+#pragma unroll
+          for (int ft = 0; ft < 2; ++ft) {
+            const float dl = fmaxf(0.f, group_max(lane_max(ft)));
+            const float alpha = fast_exp2(-dl);
+            nm[ft] -= dl;
+            NM[ft] = splat(nm[ft]);
+            lvec[ft] *= alpha;
+            O[0][ft] *= alpha;
+            O[1][ft] *= alpha;
+            exp_and_sum(ft, dl);
+          }
+        }
+      }
+      lvec[0] += ps[0];
+      lvec[1] += ps[1];
+      const bf8 pb0 = pack8(P[0][0], P[1][0]), pb1 = pack8(P[0][1], P[1][1]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        O[dt][0] = EDTTS_MFMA16(VA[dt], pb0, O[dt][0]);
+        O[dt][1] = EDTTS_MFMA16(VA[dt], pb1, O[dt][1]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      load_v(hd, cnext, VA);
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    auto chunk_of = [&](int st) { return st >= nchunk ? nchunk - 1 : (st == 0 ? cdiag : (st <= cdiag ? st - 1 : st)); };
+    step(true, cdiag, chunk_of(1));
+    for (int st = 1; st < nchunk; ++st) step(false, chunk_of(st), chunk_of(st + 1));
+    bf8 ob[2];
+#pragma unroll
+    for (int ft = 0; ft < 2; ++ft) {
+      const float lt = group_sum(hsum(lvec[ft]));
+      const float inv = lt > 0.f ? 1.0f / lt : 0.f;
+      ob[ft] = pack8(O[0][ft] * inv, O[1][ft] * inv);
+    }
+    if (hd + 1 < C::HEADS) prefetch(hd + 1);
+    ktile16<C::HT>(ring, ob, delta);  // delta += Wo[:, head hd] . O
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// QKV of one layer from the packed normalised tile: q, k row-major [B][Tp][H] (slot order inside each head), v transposed
+// [B][H][Tp] (slot order inside each 32-key chunk) -- layers/attention.py:91-93
+// ---------------------------------------------------------------------------------------------------------
+template <class C>
+EDTTS_DEV void qkv_tail16(Ring16<C>& ring, const bf8 (&hn)[C::KT][2], const KArgs& a, int b, int m0, int lane) {
+  const int fq = lane & 15, g = lane >> 4;
+  const size_t rowbase = (size_t)b * a.Tp + m0 + fq;
+  __bf16* const qo = reinterpret_cast<__bf16*>(a.q_out);
+  __bf16* const ko = reinterpret_cast<__bf16*>(a.k_out);
+  __bf16* const vo = reinterpret_cast<__bf16*>(a.vT_out);
+#pragma unroll
+  for (int which = 0; which < 2; ++which) {
+    for (int p = 0; p < C::KT; ++p) {
+      f4 acc[2][2] = {{splat(0.f), splat(0.f)}, {splat(0.f), splat(0.f)}};
+      gemm16_pair<C::KT, false>(ring, hn, acc[0], acc[1]);
+      __bf16* dst = (which == 0 ? qo : ko) + rowbase * C::H + 32 * p + 8 * g;
+#pragma unroll
+      for (int ft = 0; ft < 2; ++ft)
+        __builtin_nontemporal_store(as_f4(pack8(acc[0][ft], acc[1][ft])), reinterpret_cast<f4*>(dst + (size_t)ft * 16 * C::H));
+    }
+  }
+  for (int p = 0; p < C::KT; ++p) {
+    f4 acc[2][2] = {{splat(0.f), splat(0.f)}, {splat(0.f), splat(0.f)}};
+    gemm16_pair<C::KT, true>(ring, hn, acc[0], acc[1]);  // C/D = [frame 4g+r of tile ft][feature 16(2p+u) + fq]
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      __bf16* dst = vo + ((size_t)b * C::VR + 16 * (2 * p + u) + fq) * a.Tp + m0 + 8 * g;
+      __builtin_nontemporal_store(as_f4(pack8(acc[u][0], acc[u][1])), reinterpret_cast<f4*>(dst));
+    }
+  }
+}
+
+// =========================================================================================================
+// prologue: h = in_proj(x) + pe ; AdaRMSNorm(layer 0) ; QKV(layer 0)
+// =========================================================================================================
+template <class C>
+__global__ __launch_bounds__(C::THREADS) void k_prologue16(KArgs a) {
+  const TileId tl = wave_tile(a.B, a.Tp, C::WAVES, C::WF);
+  if (!tl.valid) return;
+  const int lane = threadIdx.x & 63, fq = lane & 15, g = lane >> 4;
+  const int b = tl.b, m0 = tl.m0;
+  Ring16<C> ring;
+  ring.prime(a.stream, lane);
+  bf8 xin[C::MKT][2];
+#pragma unroll
+  for (int ft = 0; ft < 2; ++ft) {
+    const int f = m0 + 16 * ft + fq;
+    const float* xr = a.x + ((size_t)b * a.T + f) * C::MEL;
+#pragma unroll
+    for (int kt = 0; kt < C::MKT; ++kt) {
+      const int c0 = 32 * kt + 4 * g, c1 = c0 + 16;
+      const f4 v0 = (f < a.T && c0 < C::MEL) ? ldg4(xr + c0) : splat(0.f);
+      const f4 v1 = (f < a.T && c1 < C::MEL) ? ldg4(xr + c1) : splat(0.f);
+      xin[kt][ft] = pack8(v0, v1);
+    }
+  }
+  f4 h[C::HT][2];
+#pragma unroll
+  for (int nt = 0; nt < C::HT; ++nt) h[nt][0] = h[nt][1] = ldg4(a.inp_b + 16 * nt + 4 * g);
+#pragma unroll
+  for (int kt = 0; kt < C::MKT; ++kt) ktile16<C::HT>(ring, xin[kt], h);
+#pragma unroll
+  for (int ft = 0; ft < 2; ++ft) {
+    int f = m0 + 16 * ft + fq;
+    f = f < a.max_pos ? f : a.max_pos - 1;
+#pragma unroll
+    for (int nt = 0; nt < C::HT; ++nt) h[nt][ft] += ldg4(a.pe + (size_t)f * C::H + 16 * nt + 4 * g);
+  }
+  {
+    float* hp = a.h + ((size_t)b * a.Tp + m0 + fq) * C::H + 4 * g;
+#pragma unroll
+    for (int nt = 0; nt < C::HT; ++nt)
+#pragma unroll
+      for (int ft = 0; ft < 2; ++ft) stg4(hp + 16 * nt + (size_t)ft * 16 * C::H, h[nt][ft]);
+  }
+  bf8 hn[C::KT][2];
+  rms_norm_pack<C>(h, a.n1w, a.cond + (size_t)b * a.cond_bstride, g, hn);
+  qkv_tail16<C>(ring, hn, a, b, m0, lane);
+}
+
+// =========================================================================================================
+// transformer layer kernel (bf16 contractions)
+// =========================================================================================================
+template <class C, int TAIL>
+__global__ __launch_bounds__(C::THREADS) void k_layer16(KArgs a) {
+  const TileId tl = wave_tile(a.B, a.Tp, C::WAVES, C::WF);
+  if (!tl.valid) return;
+  const int lane = threadIdx.x & 63, fq = lane & 15, g = lane >> 4;
+  const int b = tl.b, m0 = tl.m0;
+  const size_t rowbase = (size_t)b * a.Tp + m0 + fq;
+  Ring16<C> ring;
+  ring.prime(a.stream, lane);
+
+  // residual tile (fp32) and the branch accumulator (see k_layer: a branch is added to the residual once, at its end)
+  f4 h[C::HT][2], delta[C::HT][2];
+  float* const hp = a.h + rowbase * C::H + 4 * g;
+#pragma unroll
+  for (int nt = 0; nt < C::HT; ++nt) {
+    const f4 pb = ldg4(a.proj_b + 16 * nt + 4 * g);
+#pragma unroll
+    for (int ft = 0; ft < 2; ++ft) {
+      h[nt][ft] = ldg4(hp + 16 * nt + (size_t)ft * 16 * C::H);
+      delta[nt][ft] = pb;
+    }
+  }
+  auto add_delta = [&]() {
+#pragma unroll
+    for (int nt = 0; nt < C::HT; ++nt)
+#pragma unroll
+      for (int ft = 0; ft < 2; ++ft) h[nt][ft] += delta[nt][ft];
+  };
+  // ---- x = x + attn(norm1(x, cond))   (transformer.py:142-146; q / k / v^T were produced by the previous kernel) ----
+  {
+    const __bf16* qrow = reinterpret_cast<const __bf16*>(a.q) + rowbase * C::H + 8 * g;
+    auto qf = [&](int hd, int ft) { return *reinterpret_cast<const bf8*>(qrow + (size_t)ft * 16 * C::H + hd * C::DH); };
+    attention16<C, true>(qf, reinterpret_cast<const __bf16*>(a.k) + (size_t)b * a.Tp * C::H,
+                         reinterpret_cast<const __bf16*>(a.vT) + (size_t)b * C::VR * a.Tp, a.Tp, a.T, a.window, m0, lane, ring, delta);
+    add_delta();
+  }
+  // ---- x = x + cross_attn(norm2(x), context)   (transformer.py:151, mla.py:118-194) ----
+  {
+    bf8 qx[C::KT][2];
+    {
+      bf8 hn[C::KT][2];
+      rms_norm_pack<C>(h, a.n2w, nullptr, g, hn);
+      for (int p = 0; p < C::KT; ++p) {
+        f4 acc[2][2] = {{splat(0.f), splat(0.f)}, {splat(0.f), splat(0.f)}};
+        gemm16_pair<C::KT, false>(ring, hn, acc[0], acc[1]);
+        // (a runtime-indexed register array would go to scratch: write through a fully unrolled select)
+#pragma unroll
+        for (int pp = 0; pp < C::KT; ++pp)
+          if (pp == p) {
+            qx[pp][0] = pack8(acc[0][0], acc[1][0]);
+            qx[pp][1] = pack8(acc[0][1], acc[1][1]);
+          }
+      }
+    }
+#pragma unroll
+    for (int nt = 0; nt < C::HT; ++nt) delta[nt][0] = delta[nt][1] = splat(0.f);
+    auto qf = [&](int hd, int ft) {
+      bf8 r = qx[0][ft];
+#pragma unroll
+      for (int pp = 1; pp < C::KT; ++pp)
+        if (pp == hd) r = qx[pp][ft];
+      return r;
+    };
+    attention16<C, false>(qf, reinterpret_cast<const __bf16*>(a.kc) + (size_t)b * a.Sp * C::H,
+                          reinterpret_cast<const __bf16*>(a.vcT) + (size_t)b * C::VR * a.Sp, a.Sp, a.S, -1, m0, lane, ring, delta);
+    add_delta();
+  }
+  // ---- x = x + ffn(norm3(x, cond))   (transformer.py:154-158, :13-49) ----
+  {
+    bf8 hn[C::KT][2];
+    rms_norm_pack<C>(h, a.n3w, a.cond + (size_t)b * a.cond_bstride + ((size_t)a.layer * 2 + 1) * 2 * C::H, g, hn);
+#pragma unroll
+    for (int nt = 0; nt < C::HT; ++nt) delta[nt][0] = delta[nt][1] = ldg4(a.down_b + 16 * nt + 4 * g);
+    for (int jp = 0; jp < C::HT; ++jp) {  // 2H hidden features = HT k-tiles of the down projection
+      f4 act[2][2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int j = 2 * jp + u;
+        const f4 vb = ldg4(a.up_b + 32 * j + 4 * g), gb = ldg4(a.up_b + 32 * j + 16 + 4 * g);
+        f4 v[2] = {splat(0.f), splat(0.f)}, gt[2] = {splat(0.f), splat(0.f)};
+        gemm16_pair<C::KT, false>(ring, hn, v, gt);
+#pragma unroll
+        for (int ft = 0; ft < 2; ++ft) {
+          v[ft] += vb;
+          gt[ft] += gb;
+          const f4 e = {fast_exp2(gt[ft][0] * -1.4426950408889634f), fast_exp2(gt[ft][1] * -1.4426950408889634f),
+                        fast_exp2(gt[ft][2] * -1.4426950408889634f), fast_exp2(gt[ft][3] * -1.4426950408889634f)};
+          const f4 d = e + 1.0f;
+          const f4 rc = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1]), __builtin_amdgcn_rcpf(d[2]), __builtin_amdgcn_rcpf(d[3])};
+          act[u][ft] = (v[ft] * gt[ft]) * rc;  // SwiGLU: value * silu(gate), transformer.py:21-23
+        }
+      }
+      const bf8 ab[2] = {pack8(act[0][0], act[1][0]), pack8(act[0][1], act[1][1])};
+      ktile16<C::HT>(ring, ab, delta);
+    }
+    add_delta();
+  }
+  // ---- tail ----
+  if (TAIL == TAIL_QKV) {
+#pragma unroll
+    for (int nt = 0; nt < C::HT; ++nt)
+#pragma unroll
+      for (int ft = 0; ft < 2; ++ft) stg4(hp + 16 * nt + (size_t)ft * 16 * C::H, h[nt][ft]);
+    bf8 hn[C::KT][2];
+    rms_norm_pack<C>(h, a.n1w, a.cond + (size_t)b * a.cond_bstride + ((size_t)(a.layer + 1) * 2) * 2 * C::H, g, hn);
+    qkv_tail16<C>(ring, hn, a, b, m0, lane);
+  } else {
+    bf8 hn[C::KT][2];
+    layer_norm_pack<C>(h, a.fnw, a.fnb, g, hn);
+    for (int p = 0; p < C::MTP; ++p) {
+      f4 e[2][2] = {{splat(0.f), splat(0.f)}, {splat(0.f), splat(0.f)}};
+      gemm16_pair<C::KT, false>(ring, hn, e[0], e[1]);
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int nt = 2 * p + u;
+        if (nt >= C::MT) continue;  // the padding half of the last pair
+        const f4 ob = ldg4(a.outp_b + 16 * nt + 4 * g);
+#pragma unroll
+        for (int ft = 0; ft < 2; ++ft) {
+          const int f = m0 + 16 * ft + fq;
+          if (f >= a.T) continue;
+          tail_apply<TAIL>(a, ((size_t)b * a.T + f) * C::MEL + 16 * nt + 4 * g, e[u][ft] + ob);
+        }
+      }
+    }
+  }
+}
+
+}  // namespace edtts16

@@ -100,6 +100,7 @@ struct LayerLayout {
   size_t s_ffn;   // where the ffn part of s_body starts (entry point of the split FFN kernel)
 };
 struct Layout {
+  int BF16;  // 1: bf16 contractions (edtts_bf16.h): the fragment stream holds bf16 fragments of 16 outputs x 32 inputs
   int H, HEADS, MEL, L, DH, DHP, HT, MT, R, RT, SD, NTOK, MAXPOS, MAXCPOS, NSTEP;
   size_t tok, semp, semp_b, t1T, t1b, t3T, t3b, step, inp, inp_b, pe, cpe, fnw, fnb, outp_b, freqs;
   LayerLayout layer[kMaxLayers];
@@ -117,7 +118,12 @@ static int make_layout(const EdttsDims* d, Layout* lo) {
   if (d->hidden % 32 || d->n_mels % 16 || d->semantic_dim % 16 || d->heads < 1 || d->hidden % d->heads)
     return fail(EDTTS_ERR_UNSUPPORTED, "hidden=%d heads=%d n_mels=%d semantic_dim=%d: need hidden%%32==0, n_mels%%16==0, semantic_dim%%16==0",
                 d->hidden, d->heads, d->n_mels, d->semantic_dim);
+  if (d->compute_dtype != EDTTS_F32 && d->compute_dtype != EDTTS_BF16)
+    return fail(EDTTS_ERR_UNSUPPORTED, "compute_dtype=%d (0 = f32, 1 = bf16)", d->compute_dtype);
+  if (d->compute_dtype == EDTTS_BF16 && d->hidden != 32 * d->heads)
+    return fail(EDTTS_ERR_UNSUPPORTED, "the bf16 instance needs head_dim 32 (hidden=%d heads=%d)", d->hidden, d->heads);
   memset(lo, 0, sizeof(*lo));
+  lo->BF16 = d->compute_dtype == EDTTS_BF16;
   lo->H = d->hidden; lo->HEADS = d->heads; lo->MEL = d->n_mels; lo->L = d->layers;
   lo->DH = lo->H / lo->HEADS; lo->DHP = (lo->DH + 15) / 16 * 16; lo->HT = lo->H / 16; lo->MT = lo->MEL / 16;
   lo->R = lo->H / 2; lo->RT = lo->R / 16; lo->SD = d->semantic_dim; lo->NTOK = d->codebook_size;
@@ -140,6 +146,20 @@ static int make_layout(const EdttsDims* d, Layout* lo) {
     y.kvd = take(RT * HT * kFrag); y.kvn = take(R); y.kvu = take(2 * HT * RT * kFrag);
   }
   // contiguous fragment stream: inp qkv(0) body(0) qkv(1) body(1) ... body(L-1) outp  + one ring of slack
+  if (lo->BF16) {
+    // bf16 fragments: 16 outputs x 32 inputs = 1 KiB (= kFrag floats), see edtts_bf16.h
+    const size_t KT = H / 32, MKT = (lo->MEL + 31) / 32, MTP = (MT + 1) / 2;
+    lo->inp = o; o += MKT * HT * kFrag;  // in_proj, k-major
+    for (int l = 0; l < lo->L; ++l) {
+      LayerLayout& y = lo->layer[l];
+      y.s_qkv = o; o += 3 * HT * KT * kFrag;  // q pairs | k pairs | v pairs
+      y.s_body = o;
+      y.s_ffn = o + 3 * HT * KT * kFrag;      // proj (k-major) | q_proj (pairs) | out_proj (k-major)
+      o = y.s_ffn + HT * (4 * KT + HT) * kFrag;  // per down k-tile: up value/gate of its two hidden tiles, then the down fragments
+    }
+    lo->s_outp = o; o += MTP * 2 * KT * kFrag;  // final out_proj as n-tile pairs (the last pair may be half empty)
+    o += 2 * 16 * kFrag;
+  } else {
   lo->inp = o; o += HT * MT * kFrag;  // in_proj, n-tile pairs: the prologue kernel streams inp | qkv(0)
   for (int l = 0; l < lo->L; ++l) {
     LayerLayout& y = lo->layer[l];
@@ -150,6 +170,7 @@ static int make_layout(const EdttsDims* d, Layout* lo) {
   }
   lo->s_outp = o; o += MT * HT * kFrag;
   o += 4 * HT * kFrag;  // the stream stages two phases (+ slot padding) past the last consumed fragment
+  }
   lo->total = align64(o);
   return EDTTS_OK;
 }
@@ -235,6 +256,51 @@ __global__ void k_pack_upbias(const float* src, float* dst, int H2 /* = 2H hidde
     int j = i / 32, w = i % 32;
     dst[i] = (w < 16) ? src[16 * j + w] : src[H2 + 16 * j + (w - 16)];
   }
+}
+
+// bf16 fragments (edtts_bf16.h): tile (nt, kt) = 16 outputs x 32 inputs; lane (n = lane & 15, g = lane >> 4) holds the 8 inputs
+// k = 32 kt + slot(g, j), slot(g, j) = j < 4 ? 4 g + j : 16 + 4 g + (j - 4)
+struct PackArgs16 {
+  const float* src;
+  int ld, N, K;     // source row stride, logical rows / cols
+  int NT, KT;       // packed tile counts
+  int mode;         // 0 n-tile pairs [nt/2][kt][nt%2]; 1 k-major [kt][nt]; 2 ffn up (tile = 2*hidden tile + value|gate); 3 ffn down
+  int blk, upfr;    // ffn stream: fragments per down k-tile block, up fragments per block
+  unsigned short* dst;
+  int scale_rows;
+  float scale;
+};
+__device__ __forceinline__ unsigned short f32_to_bf16_bits(float v) {
+  const __bf16 b = (__bf16)v;  // v_cvt_pk_bf16_f32: round to nearest even, NaN stays NaN
+  return __builtin_bit_cast(unsigned short, b);
+}
+__global__ void k_pack_gemm16(PackArgs16 a) {
+  const int tile = blockIdx.x, lane = threadIdx.x;
+  const int nt = tile / a.KT, kt = tile % a.KT;
+  const int fq = lane & 15, g = lane >> 4;
+  int row;
+  bool rok;
+  size_t frag;
+  if (a.mode == 2) {
+    const int jh = nt >> 1, gate = nt & 1;
+    row = gate * (a.N / 2) + 16 * jh + fq;
+    rok = true;
+    frag = (size_t)(jh >> 1) * a.blk + (size_t)(jh & 1) * (a.upfr / 2) + 2 * kt + gate;
+  } else {
+    row = 16 * nt + fq;
+    rok = row < a.N;
+    if (a.mode == 0) frag = (size_t)(nt >> 1) * (2 * a.KT) + 2 * kt + (nt & 1);
+    else if (a.mode == 1) frag = (size_t)kt * a.NT + nt;
+    else frag = (size_t)kt * a.blk + a.upfr + nt;
+  }
+  unsigned short v[8];
+  for (int j = 0; j < 8; ++j) {
+    const int k = 32 * kt + (j < 4 ? 4 * g + j : 16 + 4 * g + (j - 4));
+    const float w = (rok && k < a.K) ? a.src[(size_t)row * a.ld + k] * (row < a.scale_rows ? a.scale : 1.0f) : 0.f;
+    v[j] = f32_to_bf16_bits(w);
+  }
+  unsigned short* d = a.dst + (frag * 64 + lane) * 8;
+  for (int j = 0; j < 8; ++j) d[j] = v[j];
 }
 
 // =========================================================================================================
@@ -490,6 +556,53 @@ __global__ __launch_bounds__(C::THREADS) void k_prologue(KArgs a) {
 // =========================================================================================================
 enum { TAIL_QKV = 0, TAIL_EPS = 1, TAIL_DDIM = 2, TAIL_DDPM = 3, TAIL_LMS = 4 };
 
+// What the last layer of a decoder forward does with its eps tile (one f4 = 4 mel bins of one frame at element index idx):
+// store it, or run the sampler's elementwise update on it right away.
+template <int TAIL>
+EDTTS_DEV void tail_apply(const KArgs& a, size_t idx, f4 ev) {
+  if (TAIL == TAIL_EPS) {
+    stg4(a.eps + idx, ev);
+  } else if (TAIL == TAIL_LMS) {
+    const f4 xv = ldg4(a.x + idx);
+    f4 hn = splat(0.f), ho = splat(0.f);
+    if (a.lms.mode >= 2) hn = ldg4(a.h_new + idx);
+    if (a.lms.mode >= 3) ho = ldg4(a.h_old + idx);
+    f4 x0, xn;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float v0, vn;
+      lms_elem(xv[r], ev[r], hn[r], ho[r], a.lms, v0, vn);
+      x0[r] = v0;
+      xn[r] = vn;
+    }
+    stg4(a.x0_hist + idx, x0);
+    if (a.x0_all) stg4(a.x0_all + idx, x0);
+    stg4(a.x_prev + idx, xn);
+  } else if (TAIL == TAIL_DDPM) {
+    // ancestral DDPM update (schedule.py:222-238): mean + [t>0] * sqrt(posterior variance) * noise
+    const f4 xv = ldg4(a.x + idx);
+    const f4 nz = a.noise ? ldg4(a.noise + idx) : philox_normal4(a.seed, a.step, (a.philox_base + idx) >> 2);
+    const DdpmCoef cf{a.p_coef1, a.p_coef2, a.p_sd};
+    f4 xp;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) xp[r] = ddpm_elem(xv[r], ev[r], nz[r], cf);
+    stg4(a.x_prev + idx, xp);
+  } else {
+    // DDIM update, same operation order as schedule.py:189-199 (no fma contraction)
+    const f4 xv = ldg4(a.x + idx);
+    f4 x0, xp;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float v0, vp;
+      ddim_elem(xv[r], ev[r], a.c_s1m, a.c_sab, a.c_sabp, a.c_dir, v0, vp);
+      x0[r] = v0;
+      xp[r] = vp;
+    }
+    stg4(a.x0 + idx, x0);
+    stg4(a.x_prev + idx, xp);
+  }
+}
+
 struct QGlobal {  // q rows in global memory, row-major [Tp][H]
   const float* base;  // row of query frame (frame tile 0, fq)
   int H;
@@ -728,52 +841,13 @@ __global__ __launch_bounds__(C::THREADS) void k_layer(KArgs a) {
         const int f = m0 + 16 * ft + fq;
         if (f >= a.T) continue;
         const size_t idx = ((size_t)b * a.T + f) * C::MEL + 16 * nt + 4 * g;
-        const f4 ev = e[ft] + ob;
-        if (TAIL == TAIL_EPS) {
-          stg4(a.eps + idx, ev);
-        } else if (TAIL == TAIL_LMS) {
-          const f4 xv = ldg4(a.x + idx);
-          f4 hn = splat(0.f), ho = splat(0.f);
-          if (a.lms.mode >= 2) hn = ldg4(a.h_new + idx);
-          if (a.lms.mode >= 3) ho = ldg4(a.h_old + idx);
-          f4 x0, xn;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            float v0, vn;
-            lms_elem(xv[r], ev[r], hn[r], ho[r], a.lms, v0, vn);
-            x0[r] = v0;
-            xn[r] = vn;
-          }
-          stg4(a.x0_hist + idx, x0);
-          if (a.x0_all) stg4(a.x0_all + idx, x0);
-          stg4(a.x_prev + idx, xn);
-        } else if (TAIL == TAIL_DDPM) {
-          // ancestral DDPM update (schedule.py:222-238): mean + [t>0] * sqrt(posterior variance) * noise
-          const f4 xv = ldg4(a.x + idx);
-          const f4 nz = a.noise ? ldg4(a.noise + idx) : philox_normal4(a.seed, a.step, (a.philox_base + idx) >> 2);
-          const DdpmCoef cf{a.p_coef1, a.p_coef2, a.p_sd};
-          f4 xp;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) xp[r] = ddpm_elem(xv[r], ev[r], nz[r], cf);
-          stg4(a.x_prev + idx, xp);
-        } else {
-          // DDIM update, same operation order as schedule.py:189-199 (no fma contraction)
-          const f4 xv = ldg4(a.x + idx);
-          f4 x0, xp;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            float v0, vp;
-            ddim_elem(xv[r], ev[r], a.c_s1m, a.c_sab, a.c_sabp, a.c_dir, v0, vp);
-            x0[r] = v0;
-            xp[r] = vp;
-          }
-          stg4(a.x0 + idx, x0);
-          stg4(a.x_prev + idx, xp);
-        }
+        tail_apply<TAIL>(a, idx, e[ft] + ob);
       }
     }
   }
 }
+
+#include "edtts_bf16.h"
 
 // =========================================================================================================
 // context kernel: ctx = token_emb[sem_idx] (or sem_proj(features)) + pe_ctx ; per layer K / V^T cache
@@ -788,7 +862,9 @@ struct CtxArgs {
   float *kc, *vcT;  // [L][B][Sp][H], [L][B][VR][Sp]
   unsigned* err;    // index-error word of the workspace
 };
-template <class C>  // always instantiated with NF = 2 (32 context tokens per wave)
+// BF16OUT: the cache is written in the bf16 images of edtts_bf16.h (K rows with each head's 32 features in slot order, V^T with
+// each chunk's 32 tokens in slot order); the arithmetic stays fp32 either way (once per call).
+template <class C, bool BF16OUT = false>  // always instantiated with NF = 2 (32 context tokens per wave)
 __global__ __launch_bounds__(64 * kCtxWaves) void k_ctx(CtxArgs a) {
   const TileId tl = wave_tile(a.B, a.Sp, kCtxWaves, 32);
   if (!tl.valid) return;  // no block-level synchronisation in this kernel
@@ -857,6 +933,41 @@ __global__ __launch_bounds__(64 * kCtxWaves) void k_ctx(CtxArgs a) {
     // kv = kv_up(c): first H outputs = K, second H = V   (mla.py:150-153)
     FragRing<C::RT> ring;
     ring.prime(a.blob + a.kvu[l], lane);
+    if (BF16OUT) {
+      unsigned short* kdst = reinterpret_cast<unsigned short*>(a.kc) + (((size_t)l * a.B + b) * a.Sp + m0 + fq) * C::H + 8 * g;
+      unsigned short* vdst = reinterpret_cast<unsigned short*>(a.vcT) + (((size_t)l * a.B + b) * C::H + 4 * g) * a.Sp + m0 +
+                             8 * (fq >> 2) + (fq & 3);  // token 16 ft + fq of the chunk sits at position 8 (fq >> 2) + 4 ft + (fq & 3)
+      for (int nt = 0; nt < 2 * C::HT; nt += 2) {
+        f4 acc[2][2] = {{splat(0.f), splat(0.f)}, {splat(0.f), splat(0.f)}};
+        gemm_phase<C::RT>(ring, cn, acc[0]);
+        gemm_phase<C::RT>(ring, cn, acc[1]);
+        if (nt < C::HT) {
+#pragma unroll
+          for (int ft = 0; ft < 2; ++ft) {
+            unsigned short v[8];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              v[r] = f32_to_bf16_bits(acc[0][ft][r]);
+              v[4 + r] = f32_to_bf16_bits(acc[1][ft][r]);
+            }
+            unsigned short* d = kdst + (size_t)ft * 16 * C::H + 16 * nt;  // pair nt/2 = head nt/2: 32 features at 32 (nt/2)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) d[j] = v[j];
+          }
+        } else {
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            unsigned short* d = vdst + (size_t)(16 * (nt + u - C::HT)) * a.Sp;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              d[(size_t)r * a.Sp] = f32_to_bf16_bits(acc[u][0][r]);
+              d[(size_t)r * a.Sp + 4] = f32_to_bf16_bits(acc[u][1][r]);
+            }
+          }
+        }
+      }
+      continue;
+    }
     float* kdst = a.kc + (((size_t)l * a.B + b) * a.Sp + m0 + fq) * C::H + 4 * g;
     float* vdst = a.vcT + (((size_t)l * a.B + b) * C::VR + 4 * g) * a.Sp + m0 + fq;
     for (int nt = 0; nt < 2 * C::HT; ++nt) {
@@ -1036,6 +1147,7 @@ struct Workspace {
 #endif
 // largest frames-per-wave of any kernel instance that serves these dims: the padded length Tp is a multiple of it
 static int wave_frames(const Layout& lo) {
+  if (lo.BF16) return 32;
   int nf = (lo.H == 160 && lo.HEADS == 4 && lo.MEL == 80) ? EDTTS_NF_DEFAULT : 2;
   if (EDTTS_NF_FFN > nf && lo.H <= 192) nf = EDTTS_NF_FFN;
   return 16 * nf;
@@ -1050,15 +1162,27 @@ static void make_workspace(const Layout& lo, int B, int T, int S, int cond_rows,
   size_t o = 0;
   auto take = [&](size_t n) { size_t r = o; o = align64(o + n); return r; };
   w->err = take(64);  // word 0: EDTTS_IDX_* bits set by kernels that had to clamp an out-of-range index
+  const size_t es = lo.BF16 ? 2 : 1;  // q / k / v^T and the cross cache hold bf16 in the bf16 instance: half the floats
   w->h = take((size_t)B * w->Tp * H);
-  w->q = take((size_t)2 * B * w->Tp * H);  // two sets each (ping-pong between layers)
-  w->k = take((size_t)2 * B * w->Tp * H);
-  w->vT = take((size_t)2 * B * w->VR * w->Tp);
-  w->kc = take((size_t)lo.L * B * w->Sp * H);
-  w->vcT = take((size_t)lo.L * B * w->VR * w->Sp);
+  w->q = take((size_t)2 * B * w->Tp * H / es);  // two sets each (ping-pong between layers)
+  w->k = take((size_t)2 * B * w->Tp * H / es);
+  w->vT = take((size_t)2 * B * w->VR * w->Tp / es);
+  w->kc = take((size_t)lo.L * B * w->Sp * H / es);
+  w->vcT = take((size_t)lo.L * B * w->VR * w->Sp / es);
   w->cond = take((size_t)cond_rows * lo.L * 2 * 2 * H + (size_t)cond_rows * H);  // AdaLN rows + t_cond scratch
   w->total = o;
 }
+
+struct DdpmStepArgs {
+  const float* noise;
+  unsigned long long seed, base;
+  unsigned step;
+};
+struct LmsStepArgs {
+  LmsCoef k;
+  const float *h_new, *h_old;
+  float *x0_hist, *x0_all;
+};
 
 template <class C>
 struct Launcher {
@@ -1109,16 +1233,8 @@ struct Launcher {
   }
 
   // one decoder forward given conditioning rows + context cache already in the workspace
-  struct DdpmStep {
-    const float* noise;
-    unsigned long long seed, base;
-    unsigned step;
-  };
-  struct LmsStep {
-    LmsCoef k;
-    const float *h_new, *h_old;
-    float *x0_hist, *x0_all;
-  };
+  using DdpmStep = DdpmStepArgs;
+  using LmsStep = LmsStepArgs;
   static int forward(const Layout& lo, const float* blob, const Workspace& ws, float* wsb, int B, int T, int S, int window,
                      const float* x, const float* cond_row, int cond_bstride, int tail, float* eps, float* x_prev, float* x0,
                      const float* coef, hipStream_t st, const DdpmStep* ddpm = nullptr, const LmsStep* lms = nullptr) {
@@ -1217,13 +1333,104 @@ struct Launcher {
   }
 };
 
+// ---- bf16 instance (edtts_bf16.h) ----------------------------------------------------------------------------
+template <class C>
+struct Launcher16 {
+  using DdpmStep = DdpmStepArgs;
+  using LmsStep = LmsStepArgs;
+  using C2 = Cfg<C::H, C::HEADS, C::MEL, 2>;  // geometry of the (fp32-arithmetic) context kernel
+  static int grid(int B, int Tp) { return (B * (Tp / C::WF) + C::WAVES - 1) / C::WAVES; }
+  static int set_attrs() { return EDTTS_OK; }  // no dynamic LDS
+  static int ctx(const Layout& lo, const float* blob, const Workspace& ws, float* wsb, int B, int S, const int64_t* sem_idx,
+                 const float* sem_feat, hipStream_t st) {
+    CtxArgs a;
+    memset(&a, 0, sizeof(a));
+    a.B = B; a.S = S; a.Sp = ws.Sp; a.L = lo.L; a.SD = lo.SD; a.n_tok = lo.NTOK; a.max_cpos = lo.MAXCPOS;
+    a.sem_idx = sem_idx; a.sem_feat = sem_feat;
+    a.tok = blob + lo.tok; a.semp = blob + lo.semp; a.semp_b = blob + lo.semp_b; a.cpe = blob + lo.cpe; a.blob = blob;
+    for (int l = 0; l < lo.L; ++l) {
+      a.kvd[l] = (unsigned)lo.layer[l].kvd; a.kvn[l] = (unsigned)lo.layer[l].kvn; a.kvu[l] = (unsigned)lo.layer[l].kvu;
+    }
+    a.kc = wsb + ws.kc; a.vcT = wsb + ws.vcT;
+    a.err = reinterpret_cast<unsigned*>(wsb + ws.err);
+    hipLaunchKernelGGL((k_ctx<C2, true>), dim3((B * (ws.Sp / 32) + kCtxWaves - 1) / kCtxWaves), dim3(64 * kCtxWaves), 0, st, a);
+    LAUNCH_CHECK("k_ctx<bf16 out>");
+    return EDTTS_OK;
+  }
+  static int forward(const Layout& lo, const float* blob, const Workspace& ws, float* wsb, int B, int T, int S, int window,
+                     const float* x, const float* cond_row, int cond_bstride, int tail, float* eps, float* x_prev, float* x0,
+                     const float* coef, hipStream_t st, const DdpmStep* ddpm = nullptr, const LmsStep* lms = nullptr) {
+    KArgs a;
+    memset(&a, 0, sizeof(a));
+    a.B = B; a.T = T; a.Tp = ws.Tp; a.S = S; a.Sp = ws.Sp; a.window = window; a.max_pos = lo.MAXPOS;
+    a.max_cpos = lo.MAXCPOS; a.n_tok = lo.NTOK; a.SD = lo.SD; a.L = lo.L;
+    a.h = wsb + ws.h;
+    a.inp_b = blob + lo.inp_b; a.pe = blob + lo.pe;
+    a.fnw = blob + lo.fnw; a.fnb = blob + lo.fnb; a.outp_b = blob + lo.outp_b;
+    a.x = x; a.cond = cond_row; a.cond_bstride = cond_bstride;
+    const int g = grid(B, ws.Tp);
+    const size_t qk_set = (size_t)B * ws.Tp * lo.H / 2, v_set = (size_t)B * ws.VR * ws.Tp / 2;  // bf16: half the floats
+    auto set_qkv = [&](int in_set, int out_set) {
+      a.q = wsb + ws.q + in_set * qk_set; a.k = wsb + ws.k + in_set * qk_set; a.vT = wsb + ws.vT + in_set * v_set;
+      a.q_out = wsb + ws.q + out_set * qk_set; a.k_out = wsb + ws.k + out_set * qk_set; a.vT_out = wsb + ws.vT + out_set * v_set;
+    };
+    set_qkv(1, 0);
+    a.n1w = blob + lo.layer[0].n1w; a.stream = blob + lo.inp; a.layer = 0;  // stream: inp | qkv(0)
+    hipLaunchKernelGGL(edtts16::k_prologue16<C>, dim3(g), dim3(C::THREADS), 0, st, a);
+    LAUNCH_CHECK("k_prologue16");
+    for (int l = 0; l < lo.L; ++l) {
+      const LayerLayout& y = lo.layer[l];
+      a.layer = l;
+      set_qkv(l & 1, (l + 1) & 1);
+      a.proj_b = blob + y.proj_b; a.n2w = blob + y.n2w; a.n3w = blob + y.n3w; a.up_b = blob + y.up_b;
+      a.down_b = blob + y.down_b; a.stream = blob + y.s_body;
+      a.kc = wsb + ws.kc + (size_t)l * B * ws.Sp * lo.H / 2;
+      a.vcT = wsb + ws.vcT + (size_t)l * B * ws.VR * ws.Sp / 2;
+      int t_eff = tail;
+      if (l + 1 < lo.L) {
+        a.n1w = blob + lo.layer[l + 1].n1w;
+        t_eff = TAIL_QKV;
+      } else if (tail == TAIL_EPS) {
+        a.eps = eps;
+      } else if (tail == TAIL_LMS) {
+        a.x_prev = x_prev;
+        a.lms = lms->k; a.h_new = lms->h_new; a.h_old = lms->h_old; a.x0_hist = lms->x0_hist; a.x0_all = lms->x0_all;
+      } else if (tail == TAIL_DDPM) {
+        a.x_prev = x_prev;
+        a.p_coef1 = coef[0]; a.p_coef2 = coef[1]; a.p_sd = coef[2];
+        a.noise = ddpm->noise; a.seed = ddpm->seed; a.philox_base = ddpm->base; a.step = ddpm->step;
+      } else {
+        a.x_prev = x_prev; a.x0 = x0;
+        a.c_s1m = coef[0]; a.c_sab = coef[1]; a.c_sabp = coef[2]; a.c_dir = coef[3];
+      }
+#define EDTTS_LAUNCH16(TL) PROF_LAUNCH(st, hipLaunchKernelGGL((edtts16::k_layer16<C, TL>), dim3(g), dim3(C::THREADS), 0, st, a))
+      switch (t_eff) {
+        case TAIL_QKV: EDTTS_LAUNCH16(TAIL_QKV); break;
+        case TAIL_EPS: EDTTS_LAUNCH16(TAIL_EPS); break;
+        case TAIL_LMS: EDTTS_LAUNCH16(TAIL_LMS); break;
+        case TAIL_DDPM: EDTTS_LAUNCH16(TAIL_DDPM); break;
+        default: EDTTS_LAUNCH16(TAIL_DDIM); break;
+      }
+#undef EDTTS_LAUNCH16
+      LAUNCH_CHECK("k_layer16");
+    }
+    return EDTTS_OK;
+  }
+};
+
 // compiled decoder shapes: (hidden, heads, n_mels)
 #define EDTTS_DISPATCH(lo, ...)                                                                          \
   do {                                                                                                   \
-    if ((lo).H == 160 && (lo).HEADS == 4 && (lo).MEL == 80) { using C = Cfg<160, 4, 80, EDTTS_NF_DEFAULT>; __VA_ARGS__; } \
-    else if ((lo).H == 256 && (lo).HEADS == 8 && (lo).MEL == 80) { using C = Cfg<256, 8, 80>; __VA_ARGS__; }     \
-    else if ((lo).H == 32 && (lo).HEADS == 2 && (lo).MEL == 80) { using C = Cfg<32, 2, 80>; __VA_ARGS__; }       \
-    else if ((lo).H == 64 && (lo).HEADS == 4 && (lo).MEL == 16) { using C = Cfg<64, 4, 16>; __VA_ARGS__; }       \
+    if ((lo).BF16) {                                                                                     \
+      if ((lo).H == 256 && (lo).HEADS == 8 && (lo).MEL == 80) { using LN = Launcher16<edtts16::Cfg16<256, 8, 80>>; __VA_ARGS__; } \
+      else if ((lo).H == 64 && (lo).HEADS == 2 && (lo).MEL == 80) { using LN = Launcher16<edtts16::Cfg16<64, 2, 80>>; __VA_ARGS__; } \
+      else return fail(EDTTS_ERR_UNSUPPORTED, "no bf16 kernel instance for hidden=%d heads=%d n_mels=%d "  \
+                       "(compiled: 256/8/80, 64/2/80)", (lo).H, (lo).HEADS, (lo).MEL);                     \
+    }                                                                                                    \
+    else if ((lo).H == 160 && (lo).HEADS == 4 && (lo).MEL == 80) { using LN = Launcher<Cfg<160, 4, 80, EDTTS_NF_DEFAULT>>; __VA_ARGS__; } \
+    else if ((lo).H == 256 && (lo).HEADS == 8 && (lo).MEL == 80) { using LN = Launcher<Cfg<256, 8, 80>>; __VA_ARGS__; }     \
+    else if ((lo).H == 32 && (lo).HEADS == 2 && (lo).MEL == 80) { using LN = Launcher<Cfg<32, 2, 80>>; __VA_ARGS__; }       \
+    else if ((lo).H == 64 && (lo).HEADS == 4 && (lo).MEL == 16) { using LN = Launcher<Cfg<64, 4, 16>>; __VA_ARGS__; }       \
     else return fail(EDTTS_ERR_UNSUPPORTED, "no kernel instance for hidden=%d heads=%d n_mels=%d "        \
                      "(compiled: 160/4/80, 256/8/80, 32/2/80, 64/4/16)", (lo).H, (lo).HEADS, (lo).MEL);   \
   } while (0)
@@ -1291,6 +1498,13 @@ static int pack_gemm(hipStream_t st, const float* src, int ld, int N, int K, int
   LAUNCH_CHECK("k_pack_gemm");
   return EDTTS_OK;
 }
+static int pack_gemm16(hipStream_t st, const float* src, int ld, int N, int K, int NT, int KT, int mode, float* dst, int blk = 0,
+                       int upfr = 0, int scale_rows = 0, float scale = 1.0f) {
+  PackArgs16 p{src, ld, N, K, NT, KT, mode, blk, upfr, reinterpret_cast<unsigned short*>(dst), scale_rows, scale};
+  hipLaunchKernelGGL(k_pack_gemm16, dim3(NT * KT), dim3(64), 0, st, p);
+  LAUNCH_CHECK("k_pack_gemm16");
+  return EDTTS_OK;
+}
 static int copy_f(hipStream_t st, const float* src, float* dst, size_t n) {
   hipLaunchKernelGGL(k_copy, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, dst, n);
   LAUNCH_CHECK("k_copy");
@@ -1324,12 +1538,17 @@ int edtts_pack_weights(const EdttsDims* dims, const void* const* slots, int n_sl
   TRY(transpose_f(st, G(G_T3_W), blob + lo.t3T, H, H));
   TRY(copy_f(st, G(G_T3_B), blob + lo.t3b, H));
   TRY(copy_f(st, G(G_STEP), blob + lo.step, (size_t)lo.NSTEP * H));
+  const int KT16 = H / 32, MKT16 = (lo.MEL + 31) / 32, MTP16 = (MT + 1) / 2;  // bf16 fragment grid (edtts_bf16.h)
+  if (lo.BF16) TRY(pack_gemm16(st, G(G_INP_W), lo.MEL, H, lo.MEL, HT, MKT16, 1, blob + lo.inp));  // k-major, head of the stream
+  else
   TRY(pack_gemm(st, G(G_INP_W), lo.MEL, H, lo.MEL, HT, MT, 0, 0, 4, DH, DHP, blob + lo.inp));  // n-tile pairs, head of the stream
   TRY(copy_f(st, G(G_INP_B), blob + lo.inp_b, H));
   TRY(copy_f(st, G(G_PE), blob + lo.pe, (size_t)lo.MAXPOS * H));
   TRY(copy_f(st, G(G_CPE), blob + lo.cpe, (size_t)lo.MAXCPOS * H));
   TRY(copy_f(st, G(G_FN_W), blob + lo.fnw, H));
   TRY(copy_f(st, G(G_FN_B), blob + lo.fnb, H));
+  if (lo.BF16) TRY(pack_gemm16(st, G(G_OUT_W), H, lo.MEL, H, 2 * MTP16, KT16, 0, blob + lo.s_outp));  // n-tile pairs (rows >= n_mels: zero)
+  else
   TRY(pack_gemm(st, G(G_OUT_W), H, lo.MEL, H, MT, HT, 0, 0, 0, DH, DHP, blob + lo.s_outp));
   TRY(copy_f(st, G(G_OUT_B), blob + lo.outp_b, lo.MEL));
   TRY(copy_f(st, G(G_FREQS), blob + lo.freqs, H / 2));
@@ -1353,6 +1572,20 @@ int edtts_pack_weights(const EdttsDims* dims, const void* const* slots, int n_sl
     // fragment stream
     // the query rows carry the softmax scale: scores come out of K Q^T in the exp2 domain, log2(e) / sqrt(head_dim)
     const float qscale = 1.4426950408889634f / sqrtf((float)DH);
+    if (lo.BF16) {
+      TRY(pack_gemm16(st, W(L_QKV_W), H, 3 * H, H, 3 * HT, KT16, 0, blob + y.s_qkv, 0, 0, H, qscale));  // q | k | v as n-tile pairs
+      float* s16 = blob + y.s_body;
+      TRY(pack_gemm16(st, W(L_PROJ_W), H, H, H, HT, KT16, 1, s16));                       // k-major: k-tile = head
+      s16 += (size_t)HT * KT16 * kFrag;
+      TRY(pack_gemm16(st, W(L_QP_W), H, H, H, HT, KT16, 0, s16, 0, 0, H, qscale));
+      s16 += (size_t)HT * KT16 * kFrag;
+      TRY(pack_gemm16(st, W(L_OP_W), H, H, H, HT, KT16, 1, s16));
+      s16 += (size_t)HT * KT16 * kFrag;
+      const int blk = 4 * KT16 + HT;  // per down k-tile: value/gate fragments of its two hidden tiles, then HT down fragments
+      TRY(pack_gemm16(st, W(L_UP_W), H, 4 * H, H, 4 * HT, KT16, 2, s16, blk, 4 * KT16));
+      TRY(pack_gemm16(st, W(L_DOWN_W), 2 * H, H, 2 * H, HT, HT, 3, s16, blk, 4 * KT16));
+      continue;
+    }
     TRY(pack_gemm(st, W(L_QKV_W), H, 3 * H, H, 3 * HT, HT, 0, 0, 4, DH, DHP, blob + y.s_qkv, H, qscale));  // n-tile pairs
     float* s = blob + y.s_body;
     TRY(pack_gemm(st, W(L_PROJ_W), H, H, lo.HEADS * DHP, HT, KPT, 0, 1, 1, DH, DHP, s));
@@ -1390,9 +1623,9 @@ int edtts_decoder_forward(const EdttsDims* dims, const void* packed, void* works
   TRY(launch_cond(lo, blob, t, step_idx, nullptr, B, wsb + ws.cond, wsb, st));
   const int bstride = lo.L * 2 * 2 * lo.H;
   EDTTS_DISPATCH(lo, {
-    TRY(Launcher<C>::set_attrs());
-    TRY(Launcher<C>::ctx(lo, blob, ws, wsb, B, S, sem_features ? nullptr : sem_idx, sem_features, st));
-    TRY(Launcher<C>::forward(lo, blob, ws, wsb, B, T, S, dims->window, x, wsb + ws.cond, bstride, TAIL_EPS, eps, nullptr,
+    TRY(LN::set_attrs());
+    TRY(LN::ctx(lo, blob, ws, wsb, B, S, sem_features ? nullptr : sem_idx, sem_features, st));
+    TRY(LN::forward(lo, blob, ws, wsb, B, T, S, dims->window, x, wsb + ws.cond, bstride, TAIL_EPS, eps, nullptr,
                              nullptr, nullptr, st));
   });
   return EDTTS_OK;
@@ -1417,11 +1650,11 @@ int edtts_generate(const EdttsDims* dims, const void* packed, void* workspace, i
   TRY(launch_cond(lo, blob, nullptr, nullptr, timesteps_host, num_steps, wsb + ws.cond, wsb, st));
   const size_t row = (size_t)lo.L * 2 * 2 * lo.H;
   EDTTS_DISPATCH(lo, {
-    TRY(Launcher<C>::set_attrs());
-    TRY(Launcher<C>::ctx(lo, blob, ws, wsb, B, S, sem_idx, nullptr, st));
+    TRY(LN::set_attrs());
+    TRY(LN::ctx(lo, blob, ws, wsb, B, S, sem_idx, nullptr, st));
     for (int i = 0; i < num_steps; ++i) {
       const float* xin = (i == 0) ? x_T : x_work;
-      TRY(Launcher<C>::forward(lo, blob, ws, wsb, B, T, S, dims->window, xin, wsb + ws.cond + i * row, 0, TAIL_DDIM, nullptr,
+      TRY(LN::forward(lo, blob, ws, wsb, B, T, S, dims->window, xin, wsb + ws.cond + i * row, 0, TAIL_DDIM, nullptr,
                                x_work, x0_out, coef_host + 4 * i, st));
     }
   });
@@ -1447,11 +1680,11 @@ int edtts_sample_multistep(const EdttsDims* dims, const void* packed, void* work
   const size_t row = (size_t)lo.L * 2 * 2 * lo.H;
   const size_t per = (size_t)B * T * lo.MEL;
   EDTTS_DISPATCH(lo, {
-    TRY(Launcher<C>::set_attrs());
-    TRY(Launcher<C>::ctx(lo, blob, ws, wsb, B, S, sem_features ? nullptr : sem_idx, sem_features, st));
+    TRY(LN::set_attrs());
+    TRY(LN::ctx(lo, blob, ws, wsb, B, S, sem_features ? nullptr : sem_idx, sem_features, st));
     for (int i = 0; i < num_steps; ++i) {
       const float* c = coef_host + 8 * i;
-      typename Launcher<C>::LmsStep ls;
+      typename LN::LmsStep ls;
       ls.k.mode = (int)c[0]; ls.k.p0 = c[1]; ls.k.p1 = c[2]; ls.k.c0 = c[3]; ls.k.c1 = c[4]; ls.k.rinv = c[5]; ls.k.cB = c[6]; ls.k.cC = c[7];
       if (ls.k.mode < 1 || ls.k.mode > 3 || ls.k.mode > i + 1) return fail(EDTTS_ERR_ARG, "step %d: bad solver mode %d", i, ls.k.mode);
       // history ring of two slots: step i writes slot i%2; newest previous = slot (i-1)%2, the one before = slot i%2
@@ -1459,7 +1692,7 @@ int edtts_sample_multistep(const EdttsDims* dims, const void* packed, void* work
       ls.h_new = hist + (size_t)((i + 1) & 1) * per;
       ls.h_old = hist + (size_t)(i & 1) * per;
       ls.x0_all = x0_all ? x0_all + (size_t)i * per : nullptr;
-      TRY(Launcher<C>::forward(lo, blob, ws, wsb, B, T, S, dims->window, i == 0 ? x_T : x_out, wsb + ws.cond + i * row, 0, TAIL_LMS,
+      TRY(LN::forward(lo, blob, ws, wsb, B, T, S, dims->window, i == 0 ? x_T : x_out, wsb + ws.cond + i * row, 0, TAIL_LMS,
                                nullptr, x_out, nullptr, nullptr, st, nullptr, &ls));
     }
   });
@@ -1485,12 +1718,12 @@ int edtts_sample_ddpm(const EdttsDims* dims, const void* packed, void* workspace
   const size_t row = (size_t)lo.L * 2 * 2 * lo.H;
   const size_t per_step = (size_t)B * T * lo.MEL;
   EDTTS_DISPATCH(lo, {
-    TRY(Launcher<C>::set_attrs());
-    TRY(Launcher<C>::ctx(lo, blob, ws, wsb, B, S, sem_idx, nullptr, st));
+    TRY(LN::set_attrs());
+    TRY(LN::ctx(lo, blob, ws, wsb, B, S, sem_idx, nullptr, st));
     for (int i = 0; i < num_steps; ++i) {
-      typename Launcher<C>::DdpmStep ds{noise_all ? noise_all + (size_t)i * per_step : nullptr, (unsigned long long)seed,
+      typename LN::DdpmStep ds{noise_all ? noise_all + (size_t)i * per_step : nullptr, (unsigned long long)seed,
                                         (unsigned long long)batch_offset * T * lo.MEL, (unsigned)i};
-      TRY(Launcher<C>::forward(lo, blob, ws, wsb, B, T, S, dims->window, i == 0 ? x_T : x_out, wsb + ws.cond + i * row, 0, TAIL_DDPM,
+      TRY(LN::forward(lo, blob, ws, wsb, B, T, S, dims->window, i == 0 ? x_T : x_out, wsb + ws.cond + i * row, 0, TAIL_DDPM,
                                nullptr, x_out, nullptr, coef_host + 3 * i, st, &ds));
     }
   });

@@ -36,11 +36,17 @@ def _attach(root: nn.Module, key: str, tensor: torch.Tensor, is_buffer: bool) ->
 
 
 class EdgeDiffusionDecoder(nn.Module):
-    def __init__(self, cfg, max_len: int = 1000, max_context_len: int = 512):
+    def __init__(self, cfg, max_len: int = 1000, max_context_len: int = 512, compute_dtype: str = "f32"):
         """``max_len`` / ``max_context_len`` size the two sinusoidal tables (reference: 1000 / 512, decoder.py:38,41);
-        they are pure functions of position, so larger values only lift the reference's length limit."""
+        they are pure functions of position, so larger values only lift the reference's length limit.
+        ``compute_dtype``: "f32" (the reference's arithmetic) or "bf16" -- contractions on bf16 MFMA with fp32 accumulation,
+        residual stream / norms / softmax in fp32 (the reference's AMP precedent, utils/speed_utils.py:70; compiled for
+        head_dim 32, i.e. BASELINE config 3: hidden=256, heads=8).  Parameters stay fp32 either way."""
         super().__init__()
         self.cfg = cfg
+        if compute_dtype not in native.COMPUTE_DTYPES:
+            raise ValueError(f"compute_dtype must be one of {sorted(native.COMPUTE_DTYPES)}, got {compute_dtype!r}")
+        self.compute_dtype = compute_dtype
         self.max_len, self.max_context_len, self.n_step_emb = int(max_len), int(max_context_len), 16
         H = cfg.hidden
         for key, shape in decoder_shapes(cfg, self.max_len, self.max_context_len, self.n_step_emb).items():
@@ -135,7 +141,7 @@ class EdgeDiffusionDecoder(nn.Module):
         c = self.cfg
         window = -1 if c.attn_window_size is None else int(c.attn_window_size)
         return native.EdttsDims(c.hidden, c.layers, c.heads, c.n_mels, c.ffn_mult, c.codebook_size, c.semantic_dim, window,
-                                self.max_len, self.max_context_len, self.n_step_emb)
+                                self.max_len, self.max_context_len, self.n_step_emb, native.COMPUTE_DTYPES[self.compute_dtype])
 
     def _state_tensors(self) -> Dict[str, torch.Tensor]:
         sd = {k: v for k, v in self.named_parameters()}

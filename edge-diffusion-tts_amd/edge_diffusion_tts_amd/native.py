@@ -26,7 +26,10 @@ EXPORTED_SYMBOLS = (
 class EdttsDims(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "hidden", "layers", "heads", "n_mels", "ffn_mult", "codebook_size", "semantic_dim", "window", "max_pos",
-        "max_ctx_pos", "n_step_emb")]
+        "max_ctx_pos", "n_step_emb", "compute_dtype")]
+
+
+COMPUTE_DTYPES = {"f32": 0, "fp32": 0, "float32": 0, "bf16": 1, "bfloat16": 1}
 
 
 class EdttsError(RuntimeError):

@@ -56,7 +56,12 @@ typedef struct EdttsDims {
   int32_t max_pos;       /* rows of pos_emb.pe         (decoder.py:38: 1000) */
   int32_t max_ctx_pos;   /* rows of context_pos_emb.pe (decoder.py:41: 512)  */
   int32_t n_step_emb;    /* rows of step_emb           (decoder.py:32: 16)   */
+  int32_t compute_dtype; /* EDTTS_F32: everything fp32 (the reference's arithmetic).  EDTTS_BF16: contractions on bf16 MFMA with
+                            fp32 accumulation; residual stream, norms, softmax and sampler updates stay fp32 (the reference's AMP
+                            precedent: utils/speed_utils.py:70, train_v2.py:290).  Compiled for head_dim 32 (BASELINE config 3). */
 } EdttsDims;
+
+enum { EDTTS_F32 = 0, EDTTS_BF16 = 1 };
 
 int edtts_version(void);
 const char* edtts_last_error(void);
