@@ -15,10 +15,12 @@
 //   and the weights are packed with the same assignment: the C/D registers of two consecutive n-tiles, converted pairwise with
 //   v_cvt_pk_bf16_f32, ARE the B operand of the next GEMM's k-tile.  Nothing leaves registers inside a layer except q / k / v^T
 //   (needed by other waves) and the layer-boundary residual.
-//   Memory images follow from that: q, k and the cross K cache are row-major [frame][H] bf16 with the 32 features of a head stored
-//   in slot order (one 16-byte load per lane is an MFMA operand; q.k is order-agnostic as long as both use the same order);
-//   v^T is [H][frames] bf16 with the 32 keys of a chunk stored in slot order (position 8 g' + 4 t + r <-> key 16 t + 4 g' + r), which
-//   is what a lane of the SWAPPED product (activations as A, weights as B: C/D = [frame][feature]) holds -- one 16-byte store.
+//   Memory images follow from that.  q is row-major [frame][H] bf16 with the 32 features of a head stored in slot order (one
+//   16-byte load per lane is an MFMA operand; q.k is order-agnostic as long as both use the same order).  K (self and the cross
+//   cache) is TILE-CONTIGUOUS: [utterance][head][key tile][16 keys][32 d-slots], v^T likewise: [utterance][head][32-key chunk]
+//   [d-tile][16 d][32 key-slots] with the keys of a chunk in slot order (position 8 g' + 4 t + r <-> key 16 t + 4 g' + r), which is
+//   what a lane of the SWAPPED product (activations as A, weights as B: C/D = [frame][feature]) holds.  Every K / v^T operand
+//   tile is one contiguous KiB: one 16-byte store per lane when written, one fully coalesced load per wave when read.
 #pragma once
 
 typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
@@ -42,10 +44,14 @@ struct Cfg16 {
   static constexpr int MTP = (MT + 1) / 2;      // n-tile PAIRS of the mel dim (the last one may be half empty)
   static constexpr int R = H / 2;
   static constexpr int VR = H;                  // rows of a v^T buffer
-  static constexpr int RN = HT < 16 ? HT : 16;  // weight ring: fragments in flight per wave
   static constexpr int WAVES = 4, THREADS = 64 * WAVES;
+  // Weight stream: every GEMM unit of the kernels (an n-tile pair over all k-tiles, or one k-tile over all n-tiles) consumes
+  // exactly PH = HT fragments (1 KiB each) -- one PHASE.  The block shares one LDS ring of NS phase slots (see LdsRing).
+  static constexpr int PH = HT;                 // fragments per phase
+  static constexpr int NS = 6;                  // ring slots (phases): NS - 1 phases are in flight ahead of the consumers
+  static constexpr int LDS_BYTES = NS * PH * 1024;
   static_assert(DH == 32, "the bf16 instance is built for head_dim 32 (one MFMA k-tile per head)");
-  static_assert(H % 32 == 0 && MEL % 16 == 0 && HT % RN == 0 && (2 * KT) % RN == 0, "dims vs ring");
+  static_assert(H % 64 == 0 && MEL % 16 == 0 && PH % WAVES == 0 && LDS_BYTES <= 160 * 1024, "dims vs ring");
 };
 
 EDTTS_DEV bf8 as_bf8(f4 v) { return __builtin_bit_cast(bf8, v); }
@@ -60,38 +66,81 @@ EDTTS_DEV bf8 ldg_bf8(const __bf16* base, unsigned byte_off) {
   return *reinterpret_cast<const bf8*>(reinterpret_cast<const char*>(base) + byte_off);
 }
 
-template <class C> using Ring16 = FragRing<C::RN>;
+// ---------------------------------------------------------------------------------------------------------
+// Block-shared weight ring in LDS.  At bf16 rate a 1-KiB fragment feeds only 2 MFMAs = 32 cycles of one wave: four waves
+// streaming their own copies would ask the CU's vector L1 for 128 B/clk (it delivers 64) and keep ~1.5 MB per wave and layer
+// in flight from L2.  Instead each fragment is fetched ONCE per block by LDS-DMA (global_load_lds_dwordx4: 64 lanes x 16 B land
+// lane-contiguous = exactly the MFMA operand image, no registers involved) and read by the four waves with ds_read_b128.
+// All four waves run the same program, so the ring needs no flags: the stream is cut into PHASES of PH fragments;
+//   acquire():  s_waitcnt vmcnt(...)   this wave's share of the phase has landed (younger DMAs may stay in flight)
+//               s_barrier              => every wave's share has landed, and every wave is done reading the previous phase
+//               issue this wave's share of phase p + NS - 1 into the slot the previous phase occupied
+// i.e. one barrier per 2 * PH MFMAs, NS - 1 phases (80 KiB at H = 256) of prefetch depth.  The DMAs are always issued (the blob
+// carries NS phases of slack behind the last fragment) so that the counted wait below stays valid up to the last phase.
+// ---------------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+template <class C>
+struct LdsRing {
+  static constexpr int PH = C::PH, NS = C::NS, SHARE = C::PH / C::WAVES;
+  f4* lds;           // ring base (wave-uniform)
+  const f4* src;     // this lane's pointer to fragment 0 of the kernel's stream
+  int next;          // phase the next acquire() hands out
+  int wave, lane;
+  EDTTS_DEV void issue(int phase) {
+    const int slot = phase % NS;
+#pragma unroll
+    for (int i = 0; i < SHARE; ++i) {
+      const int f = SHARE * wave + i;
+      __builtin_amdgcn_global_load_lds(src + ((size_t)phase * PH + f) * 64, (lds_ptr_t)(lds + (slot * PH + f) * 64), 16, 0, 0);
+    }
+  }
+  EDTTS_DEV void start(const float* stream, f4* lds_base, int wave_, int lane_) {
+    lds = lds_base; wave = wave_; lane = lane_; next = 0;
+    src = reinterpret_cast<const f4*>(stream) + lane;
+    for (int p = 0; p < NS - 1; ++p) issue(p);
+  }
+  // fragments of the next phase: fragment i of this lane at ptr[i * 64]
+  EDTTS_DEV const f4* acquire() {
+    static_assert(SHARE * (NS - 2) <= 63, "vmcnt immediate");
+    // all but the SHARE * (NS - 2) youngest vector-memory operations done => the DMAs of phase `next` (and everything older) landed
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SHARE * (NS - 2)) : "memory");
+    __builtin_amdgcn_s_barrier();
+    issue(next + NS - 1);
+    const f4* p = lds + (next % NS) * PH * 64 + lane;
+    ++next;
+    return p;
+  }
+  EDTTS_DEV void drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }  // no DMA may outlive the block's LDS allocation
+};
+template <class C> using Ring16 = LdsRing<C>;
 
-// two n-tiles at once from a stream that interleaves their fragments per k-tile ([kt][tile a | tile b]).
+// two n-tiles at once from a phase that interleaves their fragments per k-tile ([kt][tile a | tile b]).
 // SWAP: activations as the A operand, weights as B -> C/D = [frame][feature] (used for v^T).
-template <int KT, bool SWAP, int RN>
-EDTTS_DEV void gemm16_pair(FragRing<RN>& ring, const bf8 (&in)[KT][2], f4 (&a)[2], f4 (&b)[2]) {
-  static_assert((2 * KT) % RN == 0, "phase length must be a multiple of the ring size");
+template <int KT, bool SWAP, class C>
+EDTTS_DEV void gemm16_pair(LdsRing<C>& ring, const bf8 (&in)[KT][2], f4 (&a)[2], f4 (&b)[2]) {
+  static_assert(2 * KT == C::PH, "an n-tile pair over all k-tiles is one phase");
+  const f4* fr = ring.acquire();
 #pragma unroll
   for (int kt = 0; kt < KT; ++kt) {
-    const bf8 fa = as_bf8(ring.at(2 * kt)), fb = as_bf8(ring.at(2 * kt + 1));
+    const bf8 fa = as_bf8(fr[(2 * kt) * 64]), fb = as_bf8(fr[(2 * kt + 1) * 64]);
 #pragma unroll
     for (int ft = 0; ft < 2; ++ft) {
       a[ft] = SWAP ? EDTTS_MFMA16(in[kt][ft], fa, a[ft]) : EDTTS_MFMA16(fa, in[kt][ft], a[ft]);
       b[ft] = SWAP ? EDTTS_MFMA16(in[kt][ft], fb, b[ft]) : EDTTS_MFMA16(fb, in[kt][ft], b[ft]);
     }
-    ring.template refill_after<2 * KT>(2 * kt);
-    ring.template refill_after<2 * KT>(2 * kt + 1);
   }
-  ring.advance(2 * KT);
 }
-// acc[nt] += frag(nt) * in  for one k-tile of a k-major packed matrix (NT fragments)
-template <int NT, int RN>
-EDTTS_DEV void ktile16(FragRing<RN>& ring, const bf8 (&in)[2], f4 (&acc)[NT][2]) {
-  static_assert(NT % RN == 0, "phase length must be a multiple of the ring size");
+// acc[nt] += frag(nt) * in  for one k-tile of a k-major packed matrix (NT fragments = one phase)
+template <int NT, class C>
+EDTTS_DEV void ktile16(LdsRing<C>& ring, const bf8 (&in)[2], f4 (&acc)[NT][2]) {
+  static_assert(NT == C::PH, "one k-tile over all n-tiles is one phase");
+  const f4* fr = ring.acquire();
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
-    const bf8 fa = as_bf8(ring.at(nt));
+    const bf8 fa = as_bf8(fr[nt * 64]);
     acc[nt][0] = EDTTS_MFMA16(fa, in[0], acc[nt][0]);
     acc[nt][1] = EDTTS_MFMA16(fa, in[1], acc[nt][1]);
-    ring.template refill_after<NT>(nt);
   }
-  ring.advance(NT);
 }
 
 // RMSNorm (+ optional AdaLN modulation) of the residual tile, straight into packed bf16 B operands
@@ -172,9 +221,11 @@ EDTTS_DEV void layer_norm_pack(const f4 (&x)[C::HT][2], const float* __restrict_
 // qf(hd, ft): this lane's q operand (8 bf16) of head hd, query tile ft.
 // ---------------------------------------------------------------------------------------------------------
 template <class C, bool SELF, class QF>
-EDTTS_DEV void attention16(QF&& qf, const __bf16* __restrict__ Kb, const __bf16* __restrict__ VTb, int ldv, int nkeys,
+EDTTS_DEV void attention16(QF&& qf, const __bf16* __restrict__ Kb, const __bf16* __restrict__ VTb, int kpad, int nkeys,
                            int window, int m0, int lane, Ring16<C>& ring, f4 (&delta)[C::HT][2]) {
-  constexpr int H = C::H, DH = C::DH;
+  // Kb / VTb: this utterance's K / V^T images, TILE-CONTIGUOUS: K[head][key tile][16 keys][32 d-slots] and
+  // V^T[head][32-key chunk][2 d-tiles][16 d][32 key-slots] -- every MFMA operand tile is one contiguous KiB, i.e. one fully
+  // coalesced load per wave (kpad = padded key count: head stride = 32 * kpad elements in both images).
   const int fq = lane & 15, g = lane >> 4;
   const float NEG_INF = -__builtin_inff();
   // chunk geometry (one half: NF = 2), as in edtts_device.h attention_fused
@@ -206,8 +257,8 @@ EDTTS_DEV void attention16(QF&& qf, const __bf16* __restrict__ Kb, const __bf16*
     lo_d[ft] = lo;
     span[ft] = hi - lo;
   }
-  const unsigned koff = (unsigned)(fq * H + 8 * g) * 2u;    // K row of key fq, this lane's 8 k-slots
-  const unsigned voff = (unsigned)(fq * ldv + 8 * g) * 2u;  // V^T row of feature fq, this lane's 8 key slots of the chunk
+  const unsigned toff = (unsigned)(fq * 32 + 8 * g) * 2u;  // this lane's 16 bytes inside a [16][32] tile
+  const size_t hstride = (size_t)32 * kpad;               // elements between heads
   auto clampc = [&](int c) { return c < nchunk ? c : nchunk - 1; };
   auto load_k = [&](int hd, int c, bf8 (&ka)[2]) {
     c = clampc(c);
@@ -215,14 +266,14 @@ EDTTS_DEV void attention16(QF&& qf, const __bf16* __restrict__ Kb, const __bf16*
     for (int t = 0; t < 2; ++t) {
       int kt = kt_lo + 2 * c + t;
       kt = kt < kt_hi ? kt : kt_hi - 1;
-      ka[t] = ldg_bf8(Kb + (size_t)(kt << 4) * H + hd * DH, koff);
+      ka[t] = ldg_bf8(Kb + hd * hstride + (size_t)kt * 512, toff);
     }
   };
   auto load_v = [&](int hd, int c, bf8 (&va)[2]) {
     c = clampc(c);
-    const int k0 = (kt_lo + 2 * c) << 4;
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt) va[dt] = ldg_bf8(VTb + (size_t)(hd * DH + 16 * dt) * ldv + k0, voff);
+    const __bf16* vu = VTb + hd * hstride + (size_t)((kt_lo >> 1) + c) * 1024;
+    va[0] = ldg_bf8(vu, toff);
+    va[1] = ldg_bf8(vu + 512, toff);
   };
   auto chunk_is_interior = [&](int c) {
     c = clampc(c);
@@ -245,14 +296,19 @@ EDTTS_DEV void attention16(QF&& qf, const __bf16* __restrict__ Kb, const __bf16*
         for (int r = 0; r < 4; ++r) S[t][ft][r] = (unsigned)(d0 + bias + 16 * t + r) <= sp ? vis[ft] : NEG_INF;
     }
   };
+  // step s = 0: the diagonal chunk; steps 1 .. nchunk-1: the other chunks in ascending order
+  auto chunk_of = [&](int st) { return st >= nchunk ? nchunk - 1 : (st == 0 ? cdiag : (st <= cdiag ? st - 1 : st)); };
 
-  bf8 KA[2], VA[2], q[2];
+  // K / V^T operands are double-buffered: the tiles of step s + 2 are requested while step s computes (with one wave per SIMD
+  // nothing else hides an L2 round trip: measured, with a one-step distance 40 % of the wave's cycles were s_waitcnt time)
+  bf8 KA0[2], VA0[2], KA1[2], VA1[2], q[2];
   auto prefetch = [&](int hd) {
     q[0] = qf(hd, 0);
     q[1] = qf(hd, 1);
-    load_k(hd, cdiag, KA);
-    load_v(hd, cdiag, VA);
-    __builtin_amdgcn_sched_barrier(0);
+    load_k(hd, chunk_of(0), KA0);
+    load_v(hd, chunk_of(0), VA0);
+    load_k(hd, chunk_of(1), KA1);
+    load_v(hd, chunk_of(1), VA1);
   };
   prefetch(0);
   for (int hd = 0; hd < C::HEADS; ++hd) {
@@ -260,7 +316,7 @@ EDTTS_DEV void attention16(QF&& qf, const __bf16* __restrict__ Kb, const __bf16*
     f4 lvec[2] = {splat(0.f), splat(0.f)};
     f4 NM[2] = {splat(0.f), splat(0.f)};
     float nm[2] = {0.f, 0.f};
-    auto step = [&](bool first, int c, int cnext) {
+    auto step = [&](bool first, int c, int cnext2, bf8 (&KA)[2], bf8 (&VA)[2]) {
       f4 S[2][2];
       if (chunk_is_interior(c)) {
 #pragma unroll
@@ -274,9 +330,7 @@ EDTTS_DEV void attention16(QF&& qf, const __bf16* __restrict__ Kb, const __bf16*
       for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int ft = 0; ft < 2; ++ft) S[t][ft] = EDTTS_MFMA16(KA[t], q[ft], S[t][ft]);
-      __builtin_amdgcn_sched_barrier(0);
-      load_k(hd, cnext, KA);
-      __builtin_amdgcn_sched_barrier(0);
+      load_k(hd, cnext2, KA);  // (re-reads a valid tile past the last step)
       f4 P[2][2], ps[2];
       auto lane_max = [&](int ft) {
         f4 mv = S[0][ft];
@@ -321,19 +375,18 @@ EDTTS_DEV void attention16(QF&& qf, const __bf16* __restrict__ Kb, const __bf16*
       lvec[0] += ps[0];
       lvec[1] += ps[1];
       const bf8 pb0 = pack8(P[0][0], P[1][0]), pb1 = pack8(P[0][1], P[1][1]);
-      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt) {
         O[dt][0] = EDTTS_MFMA16(VA[dt], pb0, O[dt][0]);
         O[dt][1] = EDTTS_MFMA16(VA[dt], pb1, O[dt][1]);
       }
-      __builtin_amdgcn_sched_barrier(0);
-      load_v(hd, cnext, VA);
-      __builtin_amdgcn_sched_barrier(0);
+      load_v(hd, cnext2, VA);
     };
-    auto chunk_of = [&](int st) { return st >= nchunk ? nchunk - 1 : (st == 0 ? cdiag : (st <= cdiag ? st - 1 : st)); };
-    step(true, cdiag, chunk_of(1));
-    for (int st = 1; st < nchunk; ++st) step(false, chunk_of(st), chunk_of(st + 1));
+    step(true, chunk_of(0), chunk_of(2), KA0, VA0);
+    for (int st = 1; st < nchunk; st += 2) {
+      step(false, chunk_of(st), chunk_of(st + 2), KA1, VA1);
+      if (st + 1 < nchunk) step(false, chunk_of(st + 1), chunk_of(st + 3), KA0, VA0);
+    }
     bf8 ob[2];
 #pragma unroll
     for (int ft = 0; ft < 2; ++ft) {
@@ -351,7 +404,7 @@ EDTTS_DEV void attention16(QF&& qf, const __bf16* __restrict__ Kb, const __bf16*
 // [B][H][Tp] (slot order inside each 32-key chunk) -- layers/attention.py:91-93
 // ---------------------------------------------------------------------------------------------------------
 template <class C>
-EDTTS_DEV void qkv_tail16(Ring16<C>& ring, const bf8 (&hn)[C::KT][2], const KArgs& a, int b, int m0, int lane) {
+EDTTS_DEV void qkv_tail16(Ring16<C>& ring, const bf8 (&hn)[C::KT][2], const KArgs& a, int b, int m0, int lane, bool valid) {
   const int fq = lane & 15, g = lane >> 4;
   const size_t rowbase = (size_t)b * a.Tp + m0 + fq;
   __bf16* const qo = reinterpret_cast<__bf16*>(a.q_out);
@@ -362,10 +415,14 @@ EDTTS_DEV void qkv_tail16(Ring16<C>& ring, const bf8 (&hn)[C::KT][2], const KArg
     for (int p = 0; p < C::KT; ++p) {
       f4 acc[2][2] = {{splat(0.f), splat(0.f)}, {splat(0.f), splat(0.f)}};
       gemm16_pair<C::KT, false>(ring, hn, acc[0], acc[1]);
-      __bf16* dst = (which == 0 ? qo : ko) + rowbase * C::H + 32 * p + 8 * g;
+      // q: row-major [frame][H] (read back by this wave only); k: tile-contiguous image [head p][key tile][16 keys][32 slots]
+      __bf16* dst = which == 0 ? qo + rowbase * C::H + 32 * p + 8 * g
+                               : ko + ((size_t)(b * C::HEADS + p) * (a.Tp >> 4) + (m0 >> 4)) * 512 + fq * 32 + 8 * g;
+      const size_t fstride = which == 0 ? (size_t)16 * C::H : 512;
+      if (valid)
 #pragma unroll
       for (int ft = 0; ft < 2; ++ft)
-        __builtin_nontemporal_store(as_f4(pack8(acc[0][ft], acc[1][ft])), reinterpret_cast<f4*>(dst + (size_t)ft * 16 * C::H));
+        __builtin_nontemporal_store(as_f4(pack8(acc[0][ft], acc[1][ft])), reinterpret_cast<f4*>(dst + ft * fstride));
     }
   }
   for (int p = 0; p < C::KT; ++p) {
@@ -373,8 +430,9 @@ EDTTS_DEV void qkv_tail16(Ring16<C>& ring, const bf8 (&hn)[C::KT][2], const KArg
     gemm16_pair<C::KT, true>(ring, hn, acc[0], acc[1]);  // C/D = [frame 4g+r of tile ft][feature 16(2p+u) + fq]
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      __bf16* dst = vo + ((size_t)b * C::VR + 16 * (2 * p + u) + fq) * a.Tp + m0 + 8 * g;
-      __builtin_nontemporal_store(as_f4(pack8(acc[u][0], acc[u][1])), reinterpret_cast<f4*>(dst));
+      // v^T image: [head p][32-key chunk][d-tile u][16 d][32 key slots]
+      __bf16* dst = vo + ((size_t)(b * C::HEADS + p) * (a.Tp >> 5) + (m0 >> 5)) * 1024 + u * 512 + fq * 32 + 8 * g;
+      if (valid) __builtin_nontemporal_store(as_f4(pack8(acc[u][0], acc[u][1])), reinterpret_cast<f4*>(dst));
     }
   }
 }
@@ -384,12 +442,15 @@ EDTTS_DEV void qkv_tail16(Ring16<C>& ring, const bf8 (&hn)[C::KT][2], const KArg
 // =========================================================================================================
 template <class C>
 __global__ __launch_bounds__(C::THREADS) void k_prologue16(KArgs a) {
+  extern __shared__ __attribute__((aligned(16))) f4 ring_lds16[];
+  // (a padding wave of the last block works on a copy of the last tile -- it takes part in the ring's barriers and DMAs -- and
+  // stores nothing)
   const TileId tl = wave_tile(a.B, a.Tp, C::WAVES, C::WF);
-  if (!tl.valid) return;
+  const bool valid = tl.valid;
   const int lane = threadIdx.x & 63, fq = lane & 15, g = lane >> 4;
   const int b = tl.b, m0 = tl.m0;
   Ring16<C> ring;
-  ring.prime(a.stream, lane);
+  ring.start(a.stream, ring_lds16, __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane);
   bf8 xin[C::MKT][2];
 #pragma unroll
   for (int ft = 0; ft < 2; ++ft) {
@@ -415,7 +476,7 @@ __global__ __launch_bounds__(C::THREADS) void k_prologue16(KArgs a) {
 #pragma unroll
     for (int nt = 0; nt < C::HT; ++nt) h[nt][ft] += ldg4(a.pe + (size_t)f * C::H + 16 * nt + 4 * g);
   }
-  {
+  if (valid) {
     float* hp = a.h + ((size_t)b * a.Tp + m0 + fq) * C::H + 4 * g;
 #pragma unroll
     for (int nt = 0; nt < C::HT; ++nt)
@@ -424,7 +485,8 @@ __global__ __launch_bounds__(C::THREADS) void k_prologue16(KArgs a) {
   }
   bf8 hn[C::KT][2];
   rms_norm_pack<C>(h, a.n1w, a.cond + (size_t)b * a.cond_bstride, g, hn);
-  qkv_tail16<C>(ring, hn, a, b, m0, lane);
+  qkv_tail16<C>(ring, hn, a, b, m0, lane, valid);
+  ring.drain();
 }
 
 // =========================================================================================================
@@ -432,13 +494,14 @@ __global__ __launch_bounds__(C::THREADS) void k_prologue16(KArgs a) {
 // =========================================================================================================
 template <class C, int TAIL>
 __global__ __launch_bounds__(C::THREADS) void k_layer16(KArgs a) {
+  extern __shared__ __attribute__((aligned(16))) f4 ring_lds16[];
   const TileId tl = wave_tile(a.B, a.Tp, C::WAVES, C::WF);
-  if (!tl.valid) return;
+  const bool valid = tl.valid;  // a padding wave works on a copy of the last tile (ring barriers, DMAs) and stores nothing
   const int lane = threadIdx.x & 63, fq = lane & 15, g = lane >> 4;
   const int b = tl.b, m0 = tl.m0;
   const size_t rowbase = (size_t)b * a.Tp + m0 + fq;
   Ring16<C> ring;
-  ring.prime(a.stream, lane);
+  ring.start(a.stream, ring_lds16, __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane);
 
   // residual tile (fp32) and the branch accumulator (see k_layer: a branch is added to the residual once, at its end)
   f4 h[C::HT][2], delta[C::HT][2];
@@ -463,7 +526,7 @@ __global__ __launch_bounds__(C::THREADS) void k_layer16(KArgs a) {
     const __bf16* qrow = reinterpret_cast<const __bf16*>(a.q) + rowbase * C::H + 8 * g;
     auto qf = [&](int hd, int ft) { return *reinterpret_cast<const bf8*>(qrow + (size_t)ft * 16 * C::H + hd * C::DH); };
     attention16<C, true>(qf, reinterpret_cast<const __bf16*>(a.k) + (size_t)b * a.Tp * C::H,
-                         reinterpret_cast<const __bf16*>(a.vT) + (size_t)b * C::VR * a.Tp, a.Tp, a.T, a.window, m0, lane, ring, delta);
+                         reinterpret_cast<const __bf16*>(a.vT) + (size_t)b * C::H * a.Tp, a.Tp, a.T, a.window, m0, lane, ring, delta);
     add_delta();
   }
   // ---- x = x + cross_attn(norm2(x), context)   (transformer.py:151, mla.py:118-194) ----
@@ -494,7 +557,7 @@ __global__ __launch_bounds__(C::THREADS) void k_layer16(KArgs a) {
       return r;
     };
     attention16<C, false>(qf, reinterpret_cast<const __bf16*>(a.kc) + (size_t)b * a.Sp * C::H,
-                          reinterpret_cast<const __bf16*>(a.vcT) + (size_t)b * C::VR * a.Sp, a.Sp, a.S, -1, m0, lane, ring, delta);
+                          reinterpret_cast<const __bf16*>(a.vcT) + (size_t)b * C::H * a.Sp, a.Sp, a.S, -1, m0, lane, ring, delta);
     add_delta();
   }
   // ---- x = x + ffn(norm3(x, cond))   (transformer.py:154-158, :13-49) ----
@@ -529,13 +592,15 @@ __global__ __launch_bounds__(C::THREADS) void k_layer16(KArgs a) {
   }
   // ---- tail ----
   if (TAIL == TAIL_QKV) {
+    if (valid) {
 #pragma unroll
-    for (int nt = 0; nt < C::HT; ++nt)
+      for (int nt = 0; nt < C::HT; ++nt)
 #pragma unroll
-      for (int ft = 0; ft < 2; ++ft) stg4(hp + 16 * nt + (size_t)ft * 16 * C::H, h[nt][ft]);
+        for (int ft = 0; ft < 2; ++ft) stg4(hp + 16 * nt + (size_t)ft * 16 * C::H, h[nt][ft]);
+    }
     bf8 hn[C::KT][2];
     rms_norm_pack<C>(h, a.n1w, a.cond + (size_t)b * a.cond_bstride + ((size_t)(a.layer + 1) * 2) * 2 * C::H, g, hn);
-    qkv_tail16<C>(ring, hn, a, b, m0, lane);
+    qkv_tail16<C>(ring, hn, a, b, m0, lane, valid);
   } else {
     bf8 hn[C::KT][2];
     layer_norm_pack<C>(h, a.fnw, a.fnb, g, hn);
@@ -550,12 +615,13 @@ __global__ __launch_bounds__(C::THREADS) void k_layer16(KArgs a) {
 #pragma unroll
         for (int ft = 0; ft < 2; ++ft) {
           const int f = m0 + 16 * ft + fq;
-          if (f >= a.T) continue;
+          if (f >= a.T || !valid) continue;
           tail_apply<TAIL>(a, ((size_t)b * a.T + f) * C::MEL + 16 * nt + 4 * g, e[u][ft] + ob);
         }
       }
     }
   }
+  ring.drain();
 }
 
 }  // namespace edtts16

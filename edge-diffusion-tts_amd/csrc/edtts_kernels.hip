@@ -158,7 +158,7 @@ static int make_layout(const EdttsDims* d, Layout* lo) {
       o = y.s_ffn + HT * (4 * KT + HT) * kFrag;  // per down k-tile: up value/gate of its two hidden tiles, then the down fragments
     }
     lo->s_outp = o; o += MTP * 2 * KT * kFrag;  // final out_proj as n-tile pairs (the last pair may be half empty)
-    o += 2 * 16 * kFrag;
+    o += 8 * HT * kFrag;  // the LDS ring prefetches NS - 1 phases (of HT fragments) past the last consumed one
   } else {
   lo->inp = o; o += HT * MT * kFrag;  // in_proj, n-tile pairs: the prologue kernel streams inp | qkv(0)
   for (int l = 0; l < lo->L; ++l) {
@@ -934,9 +934,10 @@ __global__ __launch_bounds__(64 * kCtxWaves) void k_ctx(CtxArgs a) {
     FragRing<C::RT> ring;
     ring.prime(a.blob + a.kvu[l], lane);
     if (BF16OUT) {
-      unsigned short* kdst = reinterpret_cast<unsigned short*>(a.kc) + (((size_t)l * a.B + b) * a.Sp + m0 + fq) * C::H + 8 * g;
-      unsigned short* vdst = reinterpret_cast<unsigned short*>(a.vcT) + (((size_t)l * a.B + b) * C::H + 4 * g) * a.Sp + m0 +
-                             8 * (fq >> 2) + (fq & 3);  // token 16 ft + fq of the chunk sits at position 8 (fq >> 2) + 4 ft + (fq & 3)
+      // tile-contiguous images (edtts_bf16.h): K[head][token tile][16 tokens][32 slots], V^T[head][32-token chunk][d-tile][16 d][32 slots]
+      unsigned short* const kimg = reinterpret_cast<unsigned short*>(a.kc) + ((size_t)l * a.B + b) * a.Sp * C::H;
+      unsigned short* const vimg = reinterpret_cast<unsigned short*>(a.vcT) + ((size_t)l * a.B + b) * a.Sp * C::H;
+      const size_t hstride = (size_t)32 * a.Sp;
       for (int nt = 0; nt < 2 * C::HT; nt += 2) {
         f4 acc[2][2] = {{splat(0.f), splat(0.f)}, {splat(0.f), splat(0.f)}};
         gemm_phase<C::RT>(ring, cn, acc[0]);
@@ -950,18 +951,21 @@ __global__ __launch_bounds__(64 * kCtxWaves) void k_ctx(CtxArgs a) {
               v[r] = f32_to_bf16_bits(acc[0][ft][r]);
               v[4 + r] = f32_to_bf16_bits(acc[1][ft][r]);
             }
-            unsigned short* d = kdst + (size_t)ft * 16 * C::H + 16 * nt;  // pair nt/2 = head nt/2: 32 features at 32 (nt/2)
+            unsigned short* d = kimg + (nt >> 1) * hstride + (size_t)((m0 >> 4) + ft) * 512 + fq * 32 + 8 * g;  // pair nt/2 = head nt/2
 #pragma unroll
             for (int j = 0; j < 8; ++j) d[j] = v[j];
           }
         } else {
 #pragma unroll
           for (int u = 0; u < 2; ++u) {
-            unsigned short* d = vdst + (size_t)(16 * (nt + u - C::HT)) * a.Sp;
+            // token 16 ft + fq of the chunk sits at key slot 8 (fq >> 2) + 4 ft + (fq & 3); feature 16 (nt - HT + u) + 4 g + r
+            // = head (nt - HT) / 2, d-tile u, d = 4 g + r
+            unsigned short* d = vimg + ((nt - C::HT) >> 1) * hstride + (size_t)(m0 >> 5) * 1024 + u * 512 + (4 * g) * 32 +
+                                8 * (fq >> 2) + (fq & 3);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              d[(size_t)r * a.Sp] = f32_to_bf16_bits(acc[u][0][r]);
-              d[(size_t)r * a.Sp + 4] = f32_to_bf16_bits(acc[u][1][r]);
+              d[r * 32] = f32_to_bf16_bits(acc[u][0][r]);
+              d[r * 32 + 4] = f32_to_bf16_bits(acc[u][1][r]);
             }
           }
         }
@@ -1340,7 +1344,22 @@ struct Launcher16 {
   using LmsStep = LmsStepArgs;
   using C2 = Cfg<C::H, C::HEADS, C::MEL, 2>;  // geometry of the (fp32-arithmetic) context kernel
   static int grid(int B, int Tp) { return (B * (Tp / C::WF) + C::WAVES - 1) / C::WAVES; }
-  static int set_attrs() { return EDTTS_OK; }  // no dynamic LDS
+  static int set_attrs() {  // the weight ring takes > 64 KiB of dynamic LDS: opt in once per device
+    static bool done[64] = {};
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) return fail(EDTTS_ERR_UNSUPPORTED, "device ordinal %d out of range", dev);
+    if (done[dev]) return EDTTS_OK;
+    const int lds = C::LDS_BYTES;
+    HIP_TRY(hipFuncSetAttribute((const void*)edtts16::k_prologue16<C>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    HIP_TRY(hipFuncSetAttribute((const void*)edtts16::k_layer16<C, TAIL_QKV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    HIP_TRY(hipFuncSetAttribute((const void*)edtts16::k_layer16<C, TAIL_EPS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    HIP_TRY(hipFuncSetAttribute((const void*)edtts16::k_layer16<C, TAIL_DDIM>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    HIP_TRY(hipFuncSetAttribute((const void*)edtts16::k_layer16<C, TAIL_DDPM>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    HIP_TRY(hipFuncSetAttribute((const void*)edtts16::k_layer16<C, TAIL_LMS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    done[dev] = true;
+    return EDTTS_OK;
+  }
   static int ctx(const Layout& lo, const float* blob, const Workspace& ws, float* wsb, int B, int S, const int64_t* sem_idx,
                  const float* sem_feat, hipStream_t st) {
     CtxArgs a;
@@ -1376,7 +1395,7 @@ struct Launcher16 {
     };
     set_qkv(1, 0);
     a.n1w = blob + lo.layer[0].n1w; a.stream = blob + lo.inp; a.layer = 0;  // stream: inp | qkv(0)
-    hipLaunchKernelGGL(edtts16::k_prologue16<C>, dim3(g), dim3(C::THREADS), 0, st, a);
+    hipLaunchKernelGGL(edtts16::k_prologue16<C>, dim3(g), dim3(C::THREADS), C::LDS_BYTES, st, a);
     LAUNCH_CHECK("k_prologue16");
     for (int l = 0; l < lo.L; ++l) {
       const LayerLayout& y = lo.layer[l];
@@ -1403,7 +1422,7 @@ struct Launcher16 {
         a.x_prev = x_prev; a.x0 = x0;
         a.c_s1m = coef[0]; a.c_sab = coef[1]; a.c_sabp = coef[2]; a.c_dir = coef[3];
       }
-#define EDTTS_LAUNCH16(TL) PROF_LAUNCH(st, hipLaunchKernelGGL((edtts16::k_layer16<C, TL>), dim3(g), dim3(C::THREADS), 0, st, a))
+#define EDTTS_LAUNCH16(TL) PROF_LAUNCH(st, hipLaunchKernelGGL((edtts16::k_layer16<C, TL>), dim3(g), dim3(C::THREADS), C::LDS_BYTES, st, a))
       switch (t_eff) {
         case TAIL_QKV: EDTTS_LAUNCH16(TAIL_QKV); break;
         case TAIL_EPS: EDTTS_LAUNCH16(TAIL_EPS); break;
