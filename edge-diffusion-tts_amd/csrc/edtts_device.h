@@ -751,6 +751,39 @@ EDTTS_DEV void lms_elem(float x, float out, float h_new, float h_old, const LmsC
   xn = acc;
 }
 
+// v-prediction sampler update of one element (inference_pipeline.py:127-132 / :187-192 with schedule.py:121-125,138-140), same
+// operation order, no fma contraction:  x0 = clamp(sab x - s1m v);  eps = s1m x + sab v;  x_next = san x0 + s1mn eps
+struct VpredCoef {
+  float sab, s1m, san, s1mn, cfg;
+};
+EDTTS_DEV float vpred_elem(float x, float v, const VpredCoef& k) {
+#pragma clang fp contract(off)
+  float a = k.sab * x;
+  float b = k.s1m * v;
+  float x0 = a - b;
+  x0 = fminf(fmaxf(x0, -3.0f), 3.0f);
+  float c = k.s1m * x;
+  float d = k.sab * v;
+  float e = c + d;
+  float p = k.san * x0;
+  float q = k.s1mn * e;
+  return p + q;
+}
+// q_sample (schedule.py:81-84): sqrt_ab * x0 + sqrt_1mab * noise
+EDTTS_DEV float qsample_elem(float x0, float sab, float noise, float s1m) {
+#pragma clang fp contract(off)
+  float a = sab * x0;
+  float b = s1m * noise;
+  return a + b;
+}
+// classifier-free guidance (inference_pipeline.py:183): v = v_uncond + scale * (v_cond - v_uncond)
+EDTTS_DEV float cfg_combine(float vc, float vu, float scale) {
+#pragma clang fp contract(off)
+  float d = vc - vu;
+  float s = scale * d;
+  return vu + s;
+}
+
 // Philox4x32-10 counter-based generator (Salmon et al., SC'11) -> four standard normals per call (Box-Muller).
 // counter = (element index lo, hi, step, 0), key = (seed lo, hi): every (seed, step, element) gets its own stream, so the
 // result does not depend on how elements are distributed over waves / GPUs PROVIDED the caller passes the GLOBAL element index

@@ -405,6 +405,8 @@ struct KArgs {
   unsigned long long philox_base;         // global element index of this shard's element 0 (batch_offset * T * MEL)
   unsigned step;
   LmsCoef lms;                            // multistep-solver tail
+  VpredCoef vp;                           // v-prediction in-painting sampler tail
+  const float* v_uncond;                  // ... its unconditional prediction (classifier-free guidance), or null
   const float *h_new, *h_old;             // previous x0 predictions (may alias x0_hist: read before write, same lane)
   float *x0_hist, *x0_all;                // where this step's x0 goes (history slot; optional intermediates)
 };
@@ -554,7 +556,7 @@ __global__ __launch_bounds__(C::THREADS) void k_prologue(KArgs a) {
 // =========================================================================================================
 // transformer layer kernel
 // =========================================================================================================
-enum { TAIL_QKV = 0, TAIL_EPS = 1, TAIL_DDIM = 2, TAIL_DDPM = 3, TAIL_LMS = 4 };
+enum { TAIL_QKV = 0, TAIL_EPS = 1, TAIL_DDIM = 2, TAIL_DDPM = 3, TAIL_LMS = 4, TAIL_VPRED = 5 };
 
 // What the last layer of a decoder forward does with its eps tile (one f4 = 4 mel bins of one frame at element index idx):
 // store it, or run the sampler's elementwise update on it right away.
@@ -577,6 +579,18 @@ EDTTS_DEV void tail_apply(const KArgs& a, size_t idx, f4 ev) {
     }
     stg4(a.x0_hist + idx, x0);
     if (a.x0_all) stg4(a.x0_all + idx, x0);
+    stg4(a.x_prev + idx, xn);
+  } else if (TAIL == TAIL_VPRED) {
+    // v-prediction step of the in-painting samplers, optionally with classifier-free guidance (inference_pipeline.py:125-132,179-192)
+    const f4 xv = ldg4(a.x + idx);
+    f4 v = ev, xn;
+    if (a.v_uncond) {
+      const f4 vu = ldg4(a.v_uncond + idx);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = cfg_combine(ev[r], vu[r], a.vp.cfg);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) xn[r] = vpred_elem(xv[r], v[r], a.vp);
     stg4(a.x_prev + idx, xn);
   } else if (TAIL == TAIL_DDPM) {
     // ancestral DDPM update (schedule.py:222-238): mean + [t>0] * sqrt(posterior variance) * noise
@@ -1182,6 +1196,10 @@ struct DdpmStepArgs {
   unsigned long long seed, base;
   unsigned step;
 };
+struct VpredStepArgs {
+  VpredCoef k;
+  const float* v_uncond;
+};
 struct LmsStepArgs {
   LmsCoef k;
   const float *h_new, *h_old;
@@ -1241,7 +1259,8 @@ struct Launcher {
   using LmsStep = LmsStepArgs;
   static int forward(const Layout& lo, const float* blob, const Workspace& ws, float* wsb, int B, int T, int S, int window,
                      const float* x, const float* cond_row, int cond_bstride, int tail, float* eps, float* x_prev, float* x0,
-                     const float* coef, hipStream_t st, const DdpmStep* ddpm = nullptr, const LmsStep* lms = nullptr) {
+                     const float* coef, hipStream_t st, const DdpmStep* ddpm = nullptr, const LmsStep* lms = nullptr,
+                     const VpredStepArgs* vp = nullptr) {
     KArgs a;
     base_args(lo, blob, ws, wsb, B, T, S, window, &a);
     a.x = x; a.cond = cond_row; a.cond_bstride = cond_bstride;
@@ -1272,6 +1291,9 @@ struct Launcher {
       } else if (tail == TAIL_LMS) {
         a.x_prev = x_prev;
         a.lms = lms->k; a.h_new = lms->h_new; a.h_old = lms->h_old; a.x0_hist = lms->x0_hist; a.x0_all = lms->x0_all;
+      } else if (tail == TAIL_VPRED) {
+        a.x_prev = x_prev;
+        a.vp = vp->k; a.v_uncond = vp->v_uncond;
       } else if (tail == TAIL_DDPM) {
         a.x_prev = x_prev;
         a.p_coef1 = coef[0]; a.p_coef2 = coef[1]; a.p_sd = coef[2];
@@ -1294,6 +1316,7 @@ struct Launcher {
           case TAIL_EPS: EDTTS_LAUNCH_FFN(TAIL_EPS); break;
           case TAIL_LMS: EDTTS_LAUNCH_FFN(TAIL_LMS); break;
           case TAIL_DDPM: EDTTS_LAUNCH_FFN(TAIL_DDPM); break;
+          case TAIL_VPRED: EDTTS_LAUNCH_FFN(TAIL_VPRED); break;
           default: EDTTS_LAUNCH_FFN(TAIL_DDIM); break;
         }
 #undef EDTTS_LAUNCH_FFN
@@ -1305,6 +1328,7 @@ struct Launcher {
           case TAIL_EPS: EDTTS_LAUNCH_ALL(TAIL_EPS); break;
           case TAIL_LMS: EDTTS_LAUNCH_ALL(TAIL_LMS); break;
           case TAIL_DDPM: EDTTS_LAUNCH_ALL(TAIL_DDPM); break;
+          case TAIL_VPRED: EDTTS_LAUNCH_ALL(TAIL_VPRED); break;
           default: EDTTS_LAUNCH_ALL(TAIL_DDIM); break;
         }
 #undef EDTTS_LAUNCH_ALL
@@ -1331,6 +1355,7 @@ struct Launcher {
       HIP_TRY(hipFuncSetAttribute((const void*)k_layer<C, TAIL_DDIM, PART_ALL>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
       HIP_TRY(hipFuncSetAttribute((const void*)k_layer<C, TAIL_DDPM, PART_ALL>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
       HIP_TRY(hipFuncSetAttribute((const void*)k_layer<C, TAIL_LMS, PART_ALL>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+      HIP_TRY(hipFuncSetAttribute((const void*)k_layer<C, TAIL_VPRED, PART_ALL>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     }
     done[dev] = true;
     return EDTTS_OK;
@@ -1357,6 +1382,7 @@ struct Launcher16 {
     HIP_TRY(hipFuncSetAttribute((const void*)edtts16::k_layer16<C, TAIL_DDIM>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     HIP_TRY(hipFuncSetAttribute((const void*)edtts16::k_layer16<C, TAIL_DDPM>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     HIP_TRY(hipFuncSetAttribute((const void*)edtts16::k_layer16<C, TAIL_LMS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    HIP_TRY(hipFuncSetAttribute((const void*)edtts16::k_layer16<C, TAIL_VPRED>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     done[dev] = true;
     return EDTTS_OK;
   }
@@ -1378,7 +1404,8 @@ struct Launcher16 {
   }
   static int forward(const Layout& lo, const float* blob, const Workspace& ws, float* wsb, int B, int T, int S, int window,
                      const float* x, const float* cond_row, int cond_bstride, int tail, float* eps, float* x_prev, float* x0,
-                     const float* coef, hipStream_t st, const DdpmStep* ddpm = nullptr, const LmsStep* lms = nullptr) {
+                     const float* coef, hipStream_t st, const DdpmStep* ddpm = nullptr, const LmsStep* lms = nullptr,
+                     const VpredStepArgs* vp = nullptr) {
     KArgs a;
     memset(&a, 0, sizeof(a));
     a.B = B; a.T = T; a.Tp = ws.Tp; a.S = S; a.Sp = ws.Sp; a.window = window; a.max_pos = lo.MAXPOS;
@@ -1414,6 +1441,9 @@ struct Launcher16 {
       } else if (tail == TAIL_LMS) {
         a.x_prev = x_prev;
         a.lms = lms->k; a.h_new = lms->h_new; a.h_old = lms->h_old; a.x0_hist = lms->x0_hist; a.x0_all = lms->x0_all;
+      } else if (tail == TAIL_VPRED) {
+        a.x_prev = x_prev;
+        a.vp = vp->k; a.v_uncond = vp->v_uncond;
       } else if (tail == TAIL_DDPM) {
         a.x_prev = x_prev;
         a.p_coef1 = coef[0]; a.p_coef2 = coef[1]; a.p_sd = coef[2];
@@ -1428,6 +1458,7 @@ struct Launcher16 {
         case TAIL_EPS: EDTTS_LAUNCH16(TAIL_EPS); break;
         case TAIL_LMS: EDTTS_LAUNCH16(TAIL_LMS); break;
         case TAIL_DDPM: EDTTS_LAUNCH16(TAIL_DDPM); break;
+        case TAIL_VPRED: EDTTS_LAUNCH16(TAIL_VPRED); break;
         default: EDTTS_LAUNCH16(TAIL_DDIM); break;
       }
 #undef EDTTS_LAUNCH16
@@ -1744,6 +1775,80 @@ int edtts_sample_ddpm(const EdttsDims* dims, const void* packed, void* workspace
                                         (unsigned long long)batch_offset * T * lo.MEL, (unsigned)i};
       TRY(LN::forward(lo, blob, ws, wsb, B, T, S, dims->window, i == 0 ? x_T : x_out, wsb + ws.cond + i * row, 0, TAIL_DDPM,
                                nullptr, x_out, nullptr, coef_host + 3 * i, st, &ds));
+    }
+  });
+  return EDTTS_OK;
+}
+
+// x[b][f < overlap][:] = c_known * known[b][f][:] + c_noise * noise   (noise: injected [B, overlap, MEL] or Philox keyed by
+// (seed, step, global element of the [B, overlap, MEL] tensor)); c_noise = 0 -> exact copy of the known frames
+__global__ __launch_bounds__(256) void k_inpaint_inject(float* x, const float* known, const float* noise, int B, int T, int ov, int MEL,
+                                                        float c_known, float c_noise, unsigned long long seed, unsigned step) {
+  const size_t per = (size_t)ov * MEL / 4, n4 = (size_t)B * per;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t b = i / per, r = i - b * per;
+    const f4 kv = ldg4(known + 4 * i);
+    f4 o = kv;
+    if (c_noise != 0.f) {
+      const f4 nz = noise ? ldg4(noise + 4 * i) : philox_normal4(seed, step, i);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = qsample_elem(kv[e], c_known, nz[e], c_noise);
+    }
+    stg4(x + (b * T) * MEL + 4 * r, o);
+  }
+}
+
+int edtts_sample_inpaint(const EdttsDims* dims, const void* packed, void* workspace, void* workspace_uncond, int B, int T, int S,
+                         const float* sem_features, const float* zero_features, float* x, int num_steps,
+                         const int64_t* t_all, const int64_t* step_all, const float* coef_host, const float* known_mel, int overlap_len,
+                         const float* noise_k, uint64_t seed, float cfg_scale, float* v_uncond, void* stream) {
+  Layout lo;
+  TRY(make_layout(dims, &lo));
+  if (!packed || !workspace || !sem_features || !x || !t_all || !step_all || !coef_host) return fail(EDTTS_ERR_ARG, "NULL pointer argument");
+  if (num_steps < 1) return fail(EDTTS_ERR_ARG, "num_steps=%d < 1", num_steps);
+  const bool guided = cfg_scale != 1.0f;
+  if (guided && (!workspace_uncond || !zero_features || !v_uncond)) return fail(EDTTS_ERR_ARG, "cfg_scale != 1 needs workspace_uncond, zero_features and v_uncond");
+  if (known_mel && (overlap_len < 1 || overlap_len > T)) return fail(EDTTS_ERR_ARG, "overlap_len=%d outside [1,%d]", overlap_len, T);
+  TRY(check_shapes(lo, B, T, S));
+  hipStream_t st = (hipStream_t)stream;
+  const float* blob = (const float*)packed;
+  float* wsb = (float*)workspace;
+  float* wsu = (float*)workspace_uncond;
+  Workspace ws;
+  make_workspace(lo, B, T, S, num_steps, &ws);
+  TRY(launch_cond(lo, blob, t_all, step_all, nullptr, num_steps, wsb + ws.cond, wsb, st));
+  const size_t row = (size_t)lo.L * 2 * 2 * lo.H;
+  auto inject = [&](float ck, float cn, int step) {
+    const size_t n4 = (size_t)B * overlap_len * lo.MEL / 4;
+    size_t bx = (n4 + 255) / 256;
+    if (bx > 2048) bx = 2048;
+    hipLaunchKernelGGL(k_inpaint_inject, dim3((unsigned)bx), dim3(256), 0, st, x, known_mel,
+                       noise_k ? noise_k + (size_t)step * B * overlap_len * lo.MEL : nullptr, B, T, overlap_len, lo.MEL, ck, cn,
+                       (unsigned long long)seed, (unsigned)step);
+  };
+  EDTTS_DISPATCH(lo, {
+    TRY(LN::set_attrs());
+    TRY(LN::ctx(lo, blob, ws, wsb, B, S, nullptr, sem_features, st));
+    if (guided) TRY(LN::ctx(lo, blob, ws, wsu, B, S, nullptr, zero_features, st));
+    for (int i = 0; i < num_steps; ++i) {
+      const float* c = coef_host + 4 * i;  // {sqrt_ab[t], sqrt_1mab[t], sqrt(ab[t_next]), sqrt(1 - ab[t_next])}
+      if (known_mel) {
+        inject(c[0], c[1], i);  // q_sample(known_mel, t) into the first overlap_len frames (inference_pipeline.py:117-123)
+        LAUNCH_CHECK("k_inpaint_inject");
+      }
+      VpredStepArgs vp{{c[0], c[1], c[2], c[3], cfg_scale}, nullptr};
+      if (guided) {
+        // the unconditional pass shares nothing with the conditional one but x and the conditioning rows
+        TRY(LN::forward(lo, blob, ws, wsu, B, T, S, dims->window, x, wsb + ws.cond + i * row, 0, TAIL_EPS, v_uncond, nullptr, nullptr,
+                        nullptr, st));
+        vp.v_uncond = v_uncond;
+      }
+      TRY(LN::forward(lo, blob, ws, wsb, B, T, S, dims->window, x, wsb + ws.cond + i * row, 0, TAIL_VPRED, nullptr, x, nullptr, nullptr,
+                      st, nullptr, nullptr, &vp));
+    }
+    if (known_mel) {
+      inject(1.0f, 0.0f, 0);  // final force (inference_pipeline.py:135-136)
+      LAUNCH_CHECK("k_inpaint_inject");
     }
   });
   return EDTTS_OK;

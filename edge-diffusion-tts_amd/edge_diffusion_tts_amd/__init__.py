@@ -13,8 +13,9 @@ from .decoder import EdgeDiffusionDecoder
 from .inference import EdgeInference
 from .conv import DepthwiseSeparableConv
 from .synth import synth_state_dict
+from .longform import InpaintSampler
 
 __all__ = [
     "CFG", "TrainPhase", "get_device", "set_seed", "DiffusionSchedule", "DPMSolverPP", "EdgeDiffusionDecoder", "EdgeInference",
-    "DepthwiseSeparableConv", "synth_state_dict",
+    "DepthwiseSeparableConv", "synth_state_dict", "InpaintSampler",
 ]

@@ -178,11 +178,11 @@ class EdgeDiffusionDecoder(nn.Module):
             self._packed_sig = sig
         return self._packed
 
-    def workspace(self, B: int, T: int, S: int, cond_rows: int, device) -> torch.Tensor:
-        key = (B, T, S, cond_rows, str(device))
+    def workspace(self, B: int, T: int, S: int, cond_rows: int, device, tag: str = "") -> torch.Tensor:
+        key = (B, T, S, cond_rows, str(device), tag)
         ws = self._workspaces.get(key)
         if ws is None:
-            if len(self._workspaces) >= 4:
+            if len(self._workspaces) >= 6:
                 self._workspaces.clear()
             nbytes = native.workspace_bytes(self.dims(), B, T, S, cond_rows)
             ws = torch.zeros(nbytes, dtype=torch.uint8, device=device)  # must start zero-filled (padding lanes)

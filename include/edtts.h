@@ -177,6 +177,28 @@ int edtts_sample_multistep(const EdttsDims* dims, const void* packed, void* work
                            const int64_t* timesteps_host, const float* coef_host, float* hist, float* x0_all,
                            float* x_out, void* stream);
 
+/* ---- long-form in-painting sampler  (/root/reference/inference_pipeline.py:97-140 inpaint_student_sample, :145-196
+ * inpaint_teacher_refine) -------------------------------------------------------------------------------------------
+ * A v-prediction sampler on the sem_features context with a CONSTANT step index (3 for the student, 0 for the teacher).  x [B,T,
+ * n_mels] holds the start point on entry (noise, or q_sample(x_coarse, t_start) -- the host draws it) and the result on return.
+ * t_all / step_all: device int64[num_steps], the timesteps in visiting order and the (constant) step index of every step.
+ * For step i = 0 .. num_steps-1 (t = t_all[i], t_next = t_all[i+1] or 0):
+ *     if known_mel:  x[:, :overlap_len] = sqrt_ab[t] * known_mel + sqrt_1mab[t] * noise_i        (q_sample of the previous chunk's tail)
+ *     v = decoder(x, t, sem_features, step_idx)
+ *     if cfg_scale != 1:  v = v_u + cfg_scale * (v - v_u),  v_u = decoder(x, t, zero_features, step_idx)   (classifier-free guidance)
+ *     x0 = clamp(sqrt_ab[t] x - sqrt_1mab[t] v, -3, 3);  eps = sqrt_1mab[t] x + sqrt_ab[t] v
+ *     x  = sqrt(ab[t_next]) x0 + sqrt(1 - ab[t_next]) eps
+ * and finally x[:, :overlap_len] = known_mel.  The blend, the guidance combine and the update are fused into the last transformer
+ * layer of the conditional pass; the context K/V of both passes is built once.
+ * coef_host: float[num_steps*4] = {sqrt_ab[t], sqrt_1mab[t], sqrt(ab[t_next]), sqrt(1-ab[t_next])}.  known_mel [B,overlap_len,n_mels]
+ * or NULL.  noise_k [num_steps,B,overlap_len,n_mels] (the reference's torch.randn_like draws; parity runs inject them) or NULL ->
+ * in-kernel Philox keyed by (seed, step, element).  cfg_scale != 1 needs a second workspace (same size), an all-zero feature
+ * tensor [B,S,semantic_dim] and a scratch v_uncond [B,T,n_mels].  Workspaces sized with cond_rows = num_steps. */
+int edtts_sample_inpaint(const EdttsDims* dims, const void* packed, void* workspace, void* workspace_uncond, int B, int T, int S,
+                         const float* sem_features, const float* zero_features, float* x, int num_steps,
+                         const int64_t* t_all, const int64_t* step_all, const float* coef_host, const float* known_mel,
+                         int overlap_len, const float* noise_k, uint64_t seed, float cfg_scale, float* v_uncond, void* stream);
+
 /* ---- depthwise-separable Conv1d  (layers/conv.py:25-64, DepthwiseSeparableConv.forward) -----------------
  * Standalone exported layer (named by the north star; the decoder never calls it).
  * x [B,C_in,T] channel-first; dw [C_in,k] depthwise taps (stride 1, zero pad k/2, no bias); pw [C_out,C_in],

@@ -363,3 +363,58 @@ def dsconv_forward(x: Tensor, dw: Tensor, pw: Tensor, pb: Tensor, gn_w: Tensor, 
     var = (zg - mu).pow(2).mean(dim=-1, keepdim=True)
     zn = ((zg - mu) * torch.rsqrt(var + eps)).reshape(B, Co, T)
     return gelu_erf(zn * gn_w[None, :, None] + gn_b[None, :, None])
+
+
+# ------------------------------------------------------------------------------------------------
+# long-form in-painting sampler
+# ------------------------------------------------------------------------------------------------
+def linspace_times(t_start: int, n: int) -> List[int]:
+    """inference_pipeline.py:101-102,165-166 -- torch.linspace(t_start, 0, n + 1).long()[:-1]."""
+    return torch.linspace(t_start, 0, n + 1).long()[:-1].tolist()
+
+
+def inpaint_loop(sd: SD, tabs: Dict[str, Tensor], x_init: Tensor, sem_features: Tensor, times: List[int], step_idx: int,
+                 known_mel: Optional[Tensor] = None, overlap_len: int = 0, noise_k: Optional[Tensor] = None, cfg_scale: float = 1.0,
+                 *, heads: int = 4, window: Optional[int] = 64) -> Tensor:
+    """The loop shared by inference_pipeline.py:97-140 (inpaint_student_sample) and :145-196 (inpaint_teacher_refine):
+    per step -- overwrite the first `overlap_len` frames with q_sample(known_mel, t) (:117-123 / :173-176), v-prediction decoder
+    call on the sem_features context with a constant step index (:125 / :179), optional classifier-free guidance against an
+    all-zero context (:181-185), clamped x0 + eps from v (:127-129 / :187-189), deterministic step to t_next with
+    sqrt(alpha_bar[t_next]) / sqrt(1 - alpha_bar[t_next]) (:131-132 / :191-192); finally force the known frames (:135-136 / :194-195).
+    noise_k [len(times), B, overlap_len, n_mels]: the torch.randn_like(known_mel) draws of the steps."""
+    B = x_init.shape[0]
+    x = x_init.clone()
+    sab, s1m, ab = tabs["sqrt_alpha_bar"], tabs["sqrt_one_minus_alpha_bar"], tabs["alpha_bar"]
+    si = torch.full((B,), step_idx, dtype=torch.long)
+    for i, t in enumerate(times):
+        t_next = times[i + 1] if i < len(times) - 1 else 0
+        tt = torch.full((B,), t, dtype=torch.long)
+        if known_mel is not None:
+            x[:, :overlap_len, :] = sab[t] * known_mel + s1m[t] * noise_k[i]                     # schedule.py:81-84
+        v = decoder_forward(sd, x, tt, None, si, sem_features, heads=heads, window=window)
+        if cfg_scale != 1.0:
+            vu = decoder_forward(sd, x, tt, None, si, torch.zeros_like(sem_features), heads=heads, window=window)
+            v = vu + cfg_scale * (v - vu)
+        x0 = torch.clamp(sab[t] * x - s1m[t] * v, -3, 3)                                         # schedule.py:121-125
+        eps = s1m[t] * x + sab[t] * v                                                            # schedule.py:138-140
+        a_next = ab[t_next]
+        x = torch.sqrt(a_next) * x0 + torch.sqrt(1 - a_next) * eps
+    if known_mel is not None:
+        x[:, :overlap_len, :] = known_mel
+    return x
+
+
+def inpaint_student_sample(sd: SD, tabs, x_init, sem_features, known_mel=None, overlap_len=0, num_steps=4, noise_k=None, **kw) -> Tensor:
+    """inference_pipeline.py:97-140: times = linspace(T - 1, 0, num_steps + 1)[:-1], step index 3 ("stage 4")."""
+    T = tabs["alpha_bar"].shape[0]
+    return inpaint_loop(sd, tabs, x_init, sem_features, linspace_times(T - 1, num_steps), 3, known_mel, overlap_len, noise_k, 1.0, **kw)
+
+
+def inpaint_teacher_refine(sd: SD, tabs, x_coarse, sem_features, noise, known_mel=None, overlap_len=0, strength=0.2, steps=10,
+                           cfg_scale=1.0, noise_k=None, **kw) -> Tensor:
+    """inference_pipeline.py:145-196: diffuse x_coarse to t_start = int(T * strength) with `noise` (:160-162), then the loop
+    over linspace(t_start, 0, steps + 1)[:-1] with step index 0 and optional CFG."""
+    T = tabs["alpha_bar"].shape[0]
+    t_start = int(T * strength)
+    x = tabs["sqrt_alpha_bar"][t_start] * x_coarse + tabs["sqrt_one_minus_alpha_bar"][t_start] * noise
+    return inpaint_loop(sd, tabs, x, sem_features, linspace_times(t_start, steps), 0, known_mel, overlap_len, noise_k, cfg_scale, **kw)

@@ -71,7 +71,60 @@ def forward_cfg3_bf16():
     np.savez_compressed(os.path.join(OUT, "forward_cfg3_bf16.npz"), eps_autocast=npf(e16.float()))
 
 
-FIXTURES = {"forward_noadaln": forward_noadaln, "forward_fsq": forward_fsq, "forward_cfg3_bf16": forward_cfg3_bf16}
+def _extract_pipeline_closures():
+    """inpaint_student_sample / inpaint_teacher_refine are closures inside inference_pipeline.main() (which itself needs
+    torchaudio, soundfile, HuBERT and checkpoints -- none available offline).  Their source is read from /root/reference AT
+    GENERATION TIME, compiled on their own, and run on CPU with the reference package's decoder / schedule and this repo's
+    synthetic weights.  Nothing of that source is stored here or in the fixture."""
+    import ast
+    tree = ast.parse(open("/root/reference/inference_pipeline.py").read())
+    main = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "main")
+    fns = [n for n in main.body if isinstance(n, ast.FunctionDef) and n.name in ("inpaint_student_sample", "inpaint_teacher_refine")]
+    assert len(fns) == 2
+    return compile(ast.Module(body=fns, type_ignores=[]), "/root/reference/inference_pipeline.py", "exec")
+
+
+@torch.no_grad()
+def inpaint():
+    cfg = ref.CFG(device="cpu")
+    dec = make_decoder(cfg, seed=0)
+    sch = ref.DiffusionSchedule(cfg.diff_steps)
+    ns = {"torch": torch, "cfg": cfg, "device": "cpu", "schedule": sch, "student_decoder": dec, "teacher_decoder": dec}
+    exec(_extract_pipeline_closures(), ns)
+    B, T, S, ov = 1, 48, 24, 12
+    feats = rnd((B, S, cfg.semantic_dim), 71, 0)
+    known = rnd((B, ov, 80), 71, 1, 1.2)
+    x_coarse = rnd((B, T, 80), 71, 2, 1.0)
+    d = dict(sem_features=npf(feats), known_mel=npf(known), x_coarse=npf(x_coarse), overlap_len=np.array(ov))
+
+    def draws(seed, first_shape, n_steps, with_known=True):
+        torch.manual_seed(seed)
+        first = torch.randn(first_shape)
+        ks = torch.stack([torch.randn_like(known) for _ in range(n_steps)]) if with_known else None
+        return first, ks
+
+    # student: x_curr = randn(x_shape), then one randn_like(known_mel) per step (inference_pipeline.py:99,120)
+    for tag, kn, n in (("stu_known", known, 4), ("stu_free", None, 3)):
+        x0, ks = draws(5, (B, T, 80), n, kn is not None)
+        torch.manual_seed(5)
+        out = ns["inpaint_student_sample"]((B, T, 80), feats, known_mel=kn, overlap_len=ov if kn is not None else 0, num_steps=n)
+        d[f"{tag}_x_init"], d[f"{tag}_out"] = npf(x0), npf(out)
+        if ks is not None:
+            d[f"{tag}_noise_k"] = npf(ks)
+    # teacher: noise = randn_like(x_coarse), then one randn_like(known_mel) per step (inference_pipeline.py:160,174)
+    for tag, kn, n, strength, scale in (("tea_known", known, 6, 0.6, 1.0), ("tea_cfg", known, 5, 0.4, 2.0), ("tea_free_cfg", None, 4, 0.5, 1.5)):
+        nz, ks = draws(9, (B, T, 80), n, kn is not None)
+        torch.manual_seed(9)
+        out = ns["inpaint_teacher_refine"](x_coarse, feats, known_mel=kn, overlap_len=ov if kn is not None else 0, strength=strength,
+                                           steps=n, cfg_scale=scale)
+        d[f"{tag}_noise"], d[f"{tag}_out"] = npf(nz), npf(out)
+        d[f"{tag}_params"] = np.array([n, strength, scale])
+        if ks is not None:
+            d[f"{tag}_noise_k"] = npf(ks)
+    np.savez_compressed(os.path.join(OUT, "inpaint.npz"), **d)
+
+
+FIXTURES = {"inpaint": inpaint, "forward_noadaln": forward_noadaln, "forward_fsq": forward_fsq, "forward_cfg3_bf16": forward_cfg3_bf16}
 
 
 if __name__ == "__main__":

@@ -822,3 +822,43 @@ def test_bf16_unsupported_head_dim_raises():
         dec(torch.zeros(1, 32, 80, device=DEV), torch.zeros(1, dtype=torch.long, device=DEV), torch.zeros(1, 16, dtype=torch.long, device=DEV))
     with pytest.raises(ValueError):
         EdgeDiffusionDecoder(cfg, compute_dtype="fp8")
+
+
+def test_inpaint_samplers(golden):
+    """the long-form pipeline's two samplers (inference_pipeline.py:97-196) through edtts_sample_inpaint,
+    against the reference's own closures run on CPU with the same noise draws: student (4 steps, step index 3) with and without a
+    known tail, teacher refine with in-painting, with classifier-free guidance (two decoder passes per step) and without a tail."""
+    from edge_diffusion_tts_amd import InpaintSampler
+    g = golden("inpaint")
+    cfg = CFG(device=DEV)
+    dec = make_decoder(cfg, 0)
+    smp = InpaintSampler(cfg, DiffusionSchedule(cfg.diff_steps).to(DEV), dec)
+    ov = int(g["overlap_len"])
+    feats, known = cu(g["sem_features"]), cu(g["known_mel"])
+    out = smp.inpaint_student_sample(tuple(g["stu_known_x_init"].shape), feats, known, ov, 4, x_init=cu(g["stu_known_x_init"]),
+                                     noise_k=cu(g["stu_known_noise_k"])).cpu()
+    assert max_abs(out, g["stu_known_out"]) < 5e-4 and torch.equal(out[:, :ov], g["known_mel"])
+    out = smp.inpaint_student_sample(tuple(g["stu_free_x_init"].shape), feats, None, 0, 3, x_init=cu(g["stu_free_x_init"])).cpu()
+    assert max_abs(out, g["stu_free_out"]) < 5e-4
+    worst = 0.0
+    for tag, kn in (("tea_known", True), ("tea_cfg", True), ("tea_free_cfg", False)):
+        n, strength, scale = g[f"{tag}_params"].tolist()
+        out = smp.inpaint_teacher_refine(cu(g["x_coarse"]), feats, known if kn else None, ov if kn else 0, strength, int(n), scale,
+                                         noise=cu(g[f"{tag}_noise"]), noise_k=cu(g[f"{tag}_noise_k"]) if kn else None).cpu()
+        err = max_abs(out, g[f"{tag}_out"])
+        worst = max(worst, err)
+        assert err < 5e-4, (tag, err)
+        if kn:
+            assert torch.equal(out[:, :ov], g["known_mel"])
+    print(f"in-painting samplers vs the reference's closures: worst max-abs {worst:.2e}")
+    # library noise path (no injected draws): deterministic per seed, batch of 2 chunks, finite, tail forced
+    f2, k2 = feats.repeat(2, 1, 1), known.repeat(2, 1, 1)
+    a = smp.inpaint_teacher_refine(cu(g["x_coarse"]).repeat(2, 1, 1), f2, k2, ov, 0.5, 4, 1.5, seed=3)
+    b = smp.inpaint_teacher_refine(cu(g["x_coarse"]).repeat(2, 1, 1), f2, k2, ov, 0.5, 4, 1.5, seed=3)
+    assert torch.equal(a, b) and bool(torch.isfinite(a).all()) and torch.equal(a[:, :ov], k2)
+    with pytest.raises(IndexError):
+        smp.inpaint_teacher_refine(cu(g["x_coarse"]), feats, None, 0, 1.0, 4)   # t_start = 1000: outside the tables, as in the reference
+    # chunk loop: 3 chunks with a 25 % overlap, cross-faded
+    long_feats = torch.randn(1, 60, cfg.semantic_dim, generator=torch.Generator().manual_seed(1)).to(DEV)
+    mel = smp.generate_long(long_feats, total_frames=112, chunk_frames=48, overlap_frames=12, steps=3, cfg_scale=1.0, seed=4)
+    assert mel.shape == (1, 112, 80) and bool(torch.isfinite(mel).all())
