@@ -862,6 +862,7 @@ __global__ __launch_bounds__(C::THREADS) void k_layer(KArgs a) {
 }
 
 #include "edtts_bf16.h"
+#include "edtts_melpost.h"
 
 // =========================================================================================================
 // context kernel: ctx = token_emb[sem_idx] (or sem_proj(features)) + pe_ctx ; per layer K / V^T cache
@@ -1064,8 +1065,17 @@ __global__ __launch_bounds__(256) void k_ddpm(StepArgs a) {
   const float al = a.alphas[tt], ab = a.alpha_bar[tt], be = a.betas[tt];
   const DdpmCoef cf = ddpm_coef(al, ab, be, a.post_var[tt], (long)a.t[b] > 0);
   const size_t base = (size_t)b * a.n_per_batch;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n_per_batch; i += (size_t)gridDim.x * blockDim.x) {
-    const size_t o = base + i;
+  const size_t n4 = a.n_per_batch >> 2;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t o = base + 4 * i;
+    const f4 xv = ldg4(a.x + o), e = ldg4(a.eps + o), nz = ldg4(a.noise + o);
+    f4 xp;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) xp[r] = ddpm_elem(xv[r], e[r], nz[r], cf);
+    stg4(a.x_prev + o, xp);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (a.n_per_batch & 3)) {  // ragged tail (n_per_batch % 4)
+    const size_t o = base + (n4 << 2) + threadIdx.x;
     a.x_prev[o] = ddpm_elem(a.x[o], a.eps[o], a.noise[o], cf);
   }
 }
@@ -1074,70 +1084,124 @@ __global__ __launch_bounds__(256) void k_ddpm(StepArgs a) {
 // depthwise-separable conv (standalone exported layer, conv.py:25-64) -- simple, not on the timed path
 // =========================================================================================================
 // z[b][co][t] = pb[co] + sum_ci pw[co][ci] * (sum_j dw[ci][j] * x[b][ci][t + j - k/2])
-__global__ void k_dsconv_pw(const float* x, const float* dw, const float* pw, const float* pb, int B, int Ci, int Co, int T,
-                            int ks, float* z) {
-  extern __shared__ float dsm[];  // depthwise output tile [Ci][64]
-  const int b = blockIdx.y, t0 = blockIdx.x * 64, pad = ks / 2;
-  for (int i = threadIdx.x; i < Ci * 64; i += blockDim.x) {
-    const int ci = i / 64, tt = t0 + (i % 64);
+// One block = (utterance b, 64 frames): the depthwise taps go into an LDS tile [Cip][64 + 4] (Cip = C_in rounded up to 16, the
+// padding rows zero), the pointwise 1x1 conv is a [C_out x C_in] x [C_in x 64] GEMM on v_mfma_f32_16x16x4_f32 (exact fp32):
+// each of the four waves owns 16 frames; A = pw rows (one float4 of 4 consecutive ci per lane and 16-wide k-tile, MFMA step r
+// contracts ci = 16 kt + 4 g + r), B = the depthwise tile read from LDS once per wave and kept in registers for all co tiles.
+constexpr int kDsTileT = 64, kDsLd = kDsTileT + 4;
+__global__ __launch_bounds__(256) void k_dsconv_pw(const float* __restrict__ x, const float* __restrict__ dw, const float* __restrict__ pw,
+                                                   const float* __restrict__ pb, int B, int Ci, int Co, int T, int ks, float* __restrict__ z) {
+  extern __shared__ float dsm[];  // [Cip][kDsLd]
+  const int b = blockIdx.y, t0 = blockIdx.x * kDsTileT, pad = ks / 2;
+  const int Cip = (Ci + 15) & ~15;
+  for (int i = threadIdx.x; i < Cip * kDsTileT; i += blockDim.x) {
+    const int ci = i / kDsTileT, tl = i % kDsTileT, tt = t0 + tl;
     float acc = 0.f;
-    if (tt < T)
+    if (ci < Ci && tt < T) {
+      const float* xr = x + ((size_t)b * Ci + ci) * T;
       for (int j = 0; j < ks; ++j) {
         const int ts = tt + j - pad;
-        if (ts >= 0 && ts < T) acc = fmaf(x[((size_t)b * Ci + ci) * T + ts], dw[ci * ks + j], acc);
+        if (ts >= 0 && ts < T) acc = fmaf(xr[ts], dw[ci * ks + j], acc);
       }
-    dsm[i] = acc;
+    }
+    dsm[ci * kDsLd + tl] = acc;
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < Co * 64; i += blockDim.x) {
-    const int co = i / 64, tl = i % 64;
-    if (t0 + tl >= T) continue;
-    float acc = pb[co];
-    for (int ci = 0; ci < Ci; ++ci) acc = fmaf(pw[(size_t)co * Ci + ci], dsm[ci * 64 + tl], acc);
-    z[((size_t)b * Co + co) * T + t0 + tl] = acc;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fq = lane & 15, g = lane >> 4;
+  const int tl = 16 * wave + fq, tt = t0 + tl;
+  const int KT = Cip >> 4;
+  constexpr int kMaxKT = 16;  // C_in <= 256 (checked by the host)
+  f4 bt[kMaxKT];
+#pragma unroll
+  for (int kt = 0; kt < kMaxKT; ++kt) {
+    if (kt < KT) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bt[kt][r] = dsm[(16 * kt + 4 * g + r) * kDsLd + tl];
+    }
+  }
+  for (int co0 = 0; co0 < Co; co0 += 16) {
+    const int row = co0 + fq;
+    const float* wr = pw + (size_t)(row < Co ? row : Co - 1) * Ci;
+    f4 acc = splat(0.f);
+#pragma unroll
+    for (int kt = 0; kt < kMaxKT; ++kt) {
+      if (kt < KT) {
+        const int c0 = 16 * kt + 4 * g;
+        f4 a;
+        if (row < Co && c0 + 3 < Ci && (Ci & 3) == 0) a = ldg4(wr + c0);
+        else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) a[r] = (row < Co && c0 + r < Ci) ? wr[c0 + r] : 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc = EDTTS_MFMA(a[r], bt[kt][r], acc);
+      }
+    }
+    if (tt < T) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int co = co0 + 4 * g + r;
+        if (co < Co) z[((size_t)b * Co + co) * T + tt] = acc[r] + pb[co];
+      }
+    }
   }
 }
-// per (b, group) mean / rstd over (Co/groups)*T elements (two-pass, deterministic)
-__global__ void k_dsconv_stats(const float* z, int Co, int T, int groups, float* stats) {
-  __shared__ float red[256];
+// per (b, group) mean / rstd over (Co/groups)*T contiguous elements: two passes (mean, then centred sum of squares -- as accurate
+// as the reference's GroupNorm), float4 loads, wave-shuffle + one LDS hop reductions, fixed order (deterministic)
+EDTTS_DEV float block_sum256(float v, float* red) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  __syncthreads();  // (red may still be read by the previous call)
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ __launch_bounds__(256) void k_dsconv_stats(const float* __restrict__ z, int Co, int T, int groups, float* __restrict__ stats) {
+  __shared__ float red[4];
   const int bg = blockIdx.x, n = (Co / groups) * T;
   const float* p = z + (size_t)bg * n;  // groups are contiguous channel ranges
+  const bool vec = ((n & 3) == 0) && ((((size_t)bg * n) & 3) == 0);
   float s = 0.f;
-  for (int i = threadIdx.x; i < n; i += blockDim.x) s += p[i];
-  red[threadIdx.x] = s;
-  __syncthreads();
-  for (int w = 128; w > 0; w >>= 1) {
-    if (threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
-    __syncthreads();
-  }
-  const float mu = red[0] / n;
-  __syncthreads();
+  if (vec) for (int i = threadIdx.x; i < (n >> 2); i += 256) s += hsum(ldg4(p + 4 * i));
+  else for (int i = threadIdx.x; i < n; i += 256) s += p[i];
+  const float mu = block_sum256(s, red) / n;
   float v = 0.f;
-  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+  if (vec) for (int i = threadIdx.x; i < (n >> 2); i += 256) {
+    const f4 d = ldg4(p + 4 * i) - mu;
+    v += hsum(d * d);
+  }
+  else for (int i = threadIdx.x; i < n; i += 256) {
     const float d = p[i] - mu;
     v += d * d;
   }
-  red[threadIdx.x] = v;
-  __syncthreads();
-  for (int w = 128; w > 0; w >>= 1) {
-    if (threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
-    __syncthreads();
-  }
+  const float var = block_sum256(v, red) / n;
   if (threadIdx.x == 0) {
     stats[2 * bg] = mu;
-    stats[2 * bg + 1] = rsqrtf(red[0] / n + 1e-5f);
+    stats[2 * bg + 1] = rsqrtf(var + 1e-5f);
   }
 }
-__global__ void k_dsconv_norm(const float* z, const float* stats, const float* gw, const float* gb, int Co, int T, int groups,
-                              size_t total, float* y) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= total) return;
-  const int co = (int)((i / T) % Co);
-  const size_t b = i / ((size_t)T * Co);
-  const int cpg = Co / groups;
-  const size_t bg = b * groups + co / cpg;
-  const float v = (z[i] - stats[2 * bg]) * stats[2 * bg + 1] * gw[co] + gb[co];
-  y[i] = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+// y = GELU(GroupNorm(z)): one block per (b, channel), float4 along time
+__global__ __launch_bounds__(128) void k_dsconv_norm(const float* __restrict__ z, const float* __restrict__ stats, const float* __restrict__ gw,
+                                                     const float* __restrict__ gb, int Co, int T, int groups, float* __restrict__ y) {
+  const size_t bc = blockIdx.x;
+  const int co = (int)(bc % Co);
+  const size_t b = bc / Co;
+  const size_t bg = b * groups + co / (Co / groups);
+  const float mu = stats[2 * bg], rs = stats[2 * bg + 1], w = gw[co], bb = gb[co];
+  const float* zr = z + (size_t)bc * T;
+  float* yr = y + (size_t)bc * T;
+  auto f = [&](float v) {
+    v = (v - mu) * rs * w + bb;
+    return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+  };
+  if ((T & 3) == 0) {
+    for (int i = threadIdx.x; i < (T >> 2); i += 128) {
+      const f4 v = ldg4(zr + 4 * i);
+      stg4(yr + 4 * i, f4{f(v[0]), f(v[1]), f(v[2]), f(v[3])});
+    }
+  } else {
+    for (int i = threadIdx.x; i < T; i += 128) yr[i] = f(zr[i]);
+  }
 }
 
 // =========================================================================================================
@@ -1881,8 +1945,11 @@ int edtts_ddpm_step(const float* alphas, const float* alpha_bar, const float* be
   memset(&a, 0, sizeof(a));
   a.alphas = alphas; a.alpha_bar = alpha_bar; a.betas = betas; a.post_var = post_var; a.n_table = n_table;
   a.x = x; a.eps = eps; a.t = t; a.n_per_batch = n_per_batch; a.noise = noise; a.x_prev = x_prev;
-  size_t bx = (n_per_batch + 255) / 256;
+  if ((n_per_batch & 3) && (((uintptr_t)x | (uintptr_t)eps | (uintptr_t)noise | (uintptr_t)x_prev) & 15))
+    return fail(EDTTS_ERR_ARG, "tensors must be 16-byte aligned");
+  size_t bx = (n_per_batch / 4 + 255) / 256;
   if (bx > 2048) bx = 2048;
+  if (bx < 1) bx = 1;
   hipLaunchKernelGGL(k_ddpm, dim3((unsigned)bx, B), dim3(256), 0, (hipStream_t)stream, a);
   LAUNCH_CHECK("k_ddpm");
   return EDTTS_OK;
@@ -1892,18 +1959,17 @@ int edtts_dsconv_forward(const float* x, const float* dw, const float* pw, const
                          int B, int C_in, int C_out, int T, int ksize, int groups, float* scratch, float* y, void* stream) {
   if (!x || !dw || !pw || !pb || !gn_w || !gn_b || !scratch || !y) return fail(EDTTS_ERR_ARG, "NULL pointer argument");
   if (B < 1 || C_in < 1 || C_out < 1 || T < 1 || ksize < 1 || groups < 1 || C_out % groups) return fail(EDTTS_ERR_ARG, "bad sizes");
-  if ((size_t)C_in * 64 * sizeof(float) > 64 * 1024) return fail(EDTTS_ERR_UNSUPPORTED, "C_in=%d too large for the LDS tile", C_in);
+  if (C_in > 256) return fail(EDTTS_ERR_UNSUPPORTED, "C_in=%d > 256 (the depthwise tile is kept in registers per wave)", C_in);
   hipStream_t st = (hipStream_t)stream;
   float* z = scratch;
   float* stats = scratch + (size_t)B * C_out * T;
-  hipLaunchKernelGGL(k_dsconv_pw, dim3((T + 63) / 64, B), dim3(256), (size_t)C_in * 64 * sizeof(float), st, x, dw, pw, pb, B, C_in,
-                     C_out, T, ksize, z);
+  const int Cip = (C_in + 15) & ~15;
+  hipLaunchKernelGGL(k_dsconv_pw, dim3((T + kDsTileT - 1) / kDsTileT, B), dim3(256), (size_t)Cip * kDsLd * sizeof(float), st, x, dw, pw, pb,
+                     B, C_in, C_out, T, ksize, z);
   LAUNCH_CHECK("k_dsconv_pw");
   hipLaunchKernelGGL(k_dsconv_stats, dim3(B * groups), dim3(256), 0, st, z, C_out, T, groups, stats);
   LAUNCH_CHECK("k_dsconv_stats");
-  const size_t total = (size_t)B * C_out * T;
-  hipLaunchKernelGGL(k_dsconv_norm, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, z, stats, gn_w, gn_b, C_out, T, groups,
-                     total, y);
+  hipLaunchKernelGGL(k_dsconv_norm, dim3((unsigned)((size_t)B * C_out)), dim3(128), 0, st, z, stats, gn_w, gn_b, C_out, T, groups, y);
   LAUNCH_CHECK("k_dsconv_norm");
   return EDTTS_OK;
 }
@@ -1938,6 +2004,56 @@ int edtts_index_errors(void* workspace, int* flags_host, void* stream) {
   HIP_TRY(hipStreamSynchronize(st));
   if (v) HIP_TRY(hipMemsetAsync(workspace, 0, sizeof(v), st));
   *flags_host = (int)v;
+  return EDTTS_OK;
+}
+
+int edtts_mel_to_spec(const float* mel_n, const float* mean, const float* stdv, const float* pinv, int B, int T, int n_mels, int n_freqs,
+                      float* spec, void* stream) {
+  if (!mel_n || !pinv || !spec || (!mean != !stdv)) return fail(EDTTS_ERR_ARG, "NULL pointer argument (mean and std come together)");
+  if (B < 1 || T < 1 || n_mels < 1 || n_freqs < 1 || n_mels > 512) return fail(EDTTS_ERR_ARG, "bad sizes");
+  hipLaunchKernelGGL(melpost::k_mel_to_spec, dim3((T + 15) / 16, B), dim3(melpost::kThreads), 16 * n_mels * sizeof(float), (hipStream_t)stream,
+                     mel_n, mean, stdv, pinv, T, n_mels, n_freqs, spec);
+  LAUNCH_CHECK("k_mel_to_spec");
+  return EDTTS_OK;
+}
+
+int edtts_griffin_lim_scratch_floats(int B, int T, int n_fft, int hop, size_t* out_floats) {
+  if (!out_floats || B < 1 || T < 2 || hop < 1) return fail(EDTTS_ERR_ARG, "bad sizes");
+  if (n_fft != melpost::kNfft) return fail(EDTTS_ERR_UNSUPPORTED, "n_fft=%d (compiled: %d)", n_fft, melpost::kNfft);
+  const size_t bt = (size_t)B * T, Lp = (size_t)n_fft + (size_t)hop * (T - 1);
+  *out_floats = bt * melpost::kBins * 5 + bt * n_fft + (size_t)B * Lp;  // mag | angles | tprev | frames | padded signal
+  return EDTTS_OK;
+}
+
+int edtts_griffin_lim(const float* spec, int B, int T, int n_fft, int hop, const float* window, const float* twiddle, int n_iter,
+                      float momentum, float power, const float* angles0, uint64_t seed, float* scratch, float* wave_out, void* stream) {
+  if (!spec || !window || !twiddle || !scratch || !wave_out) return fail(EDTTS_ERR_ARG, "NULL pointer argument");
+  if (B < 1 || T < 2 || hop < 1 || hop > n_fft || n_iter < 0 || power <= 0.f) return fail(EDTTS_ERR_ARG, "bad sizes");
+  if (n_fft != melpost::kNfft) return fail(EDTTS_ERR_UNSUPPORTED, "n_fft=%d (compiled: %d, win_length = n_fft)", n_fft, melpost::kNfft);
+  if (hop * (T - 1) <= n_fft / 2) return fail(EDTTS_ERR_ARG, "signal of %d samples is shorter than the reflect padding (torch.stft raises too)", hop * (T - 1));
+  using namespace melpost;
+  hipStream_t st = (hipStream_t)stream;
+  const size_t bt = (size_t)B * T;
+  const int Lp = n_fft + hop * (T - 1);
+  float* mag = scratch;
+  cplx* ang = reinterpret_cast<cplx*>(mag + bt * kBins);
+  cplx* tprev = ang + bt * kBins;
+  float* frames = reinterpret_cast<float*>(tprev + bt * kBins);
+  float* wave = frames + bt * n_fft;
+  const cplx* tw = reinterpret_cast<const cplx*>(twiddle);
+  const float mom = momentum / (1.0f + momentum);
+  hipLaunchKernelGGL(k_gl_init, dim3(T, B), dim3(kThreads), 0, st, spec, angles0, T, 1.0f / power, (unsigned long long)seed, mag, ang, tprev);
+  LAUNCH_CHECK("k_gl_init");
+  int gx = (Lp + kThreads - 1) / kThreads;
+  for (int it = 0; it <= n_iter; ++it) {
+    hipLaunchKernelGGL(k_gl_istft, dim3(T, B), dim3(kThreads), 0, st, mag, ang, window, tw, T, frames);
+    hipLaunchKernelGGL(k_gl_ola, dim3(gx, B), dim3(kThreads), 0, st, frames, window, T, hop, Lp, wave);
+    if (it < n_iter) hipLaunchKernelGGL(k_gl_stft, dim3(T, B), dim3(kThreads), 0, st, wave, window, tw, T, hop, Lp, mom, ang, tprev);
+  }
+  LAUNCH_CHECK("griffin-lim kernels");
+  // torch.istft trims the centre padding: n_fft / 2 at the start, and (length = None) as much at the end
+  HIP_TRY(hipMemcpy2DAsync(wave_out, (size_t)hop * (T - 1) * sizeof(float), wave + n_fft / 2, (size_t)Lp * sizeof(float),
+                           (size_t)hop * (T - 1) * sizeof(float), B, hipMemcpyDeviceToDevice, st));
   return EDTTS_OK;
 }
 

@@ -14,8 +14,10 @@ from .inference import EdgeInference
 from .conv import DepthwiseSeparableConv
 from .synth import synth_state_dict
 from .longform import InpaintSampler
+from .melpost import GriffinLim, InverseMelScale, MelVocoder, denormalize_mel, normalize_mel
 
 __all__ = [
     "CFG", "TrainPhase", "get_device", "set_seed", "DiffusionSchedule", "DPMSolverPP", "EdgeDiffusionDecoder", "EdgeInference",
     "DepthwiseSeparableConv", "synth_state_dict", "InpaintSampler",
+    "GriffinLim", "InverseMelScale", "MelVocoder", "denormalize_mel", "normalize_mel",
 ]

@@ -20,6 +20,7 @@ EXPORTED_SYMBOLS = (
     "edtts_layer_slot_name", "edtts_packed_bytes", "edtts_pack_weights", "edtts_workspace_bytes", "edtts_decoder_forward",
     "edtts_ddim_step", "edtts_ddpm_step", "edtts_generate", "edtts_sample_ddpm", "edtts_sample_multistep", "edtts_dsconv_forward", "edtts_profile_enable",
     "edtts_profile_collect", "edtts_randn", "edtts_index_errors", "edtts_sample_inpaint",
+    "edtts_mel_to_spec", "edtts_griffin_lim_scratch_floats", "edtts_griffin_lim",
 )
 
 
@@ -69,6 +70,9 @@ def lib() -> C.CDLL:
     L.edtts_sample_ddpm.argtypes = [C.POINTER(EdttsDims), vp, vp, i32, i32, vp, vp, i32, vp, C.POINTER(f32), vp, C.c_uint64, C.c_int64, vp, vp]
     L.edtts_randn.argtypes = [vp, sz, C.c_uint64, C.c_uint32, C.c_uint64, f32, vp]
     L.edtts_index_errors.argtypes = [vp, C.POINTER(i32), vp]
+    L.edtts_mel_to_spec.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]
+    L.edtts_griffin_lim_scratch_floats.argtypes = [i32, i32, i32, i32, C.POINTER(sz)]
+    L.edtts_griffin_lim.argtypes = [vp, i32, i32, i32, i32, vp, vp, i32, f32, f32, vp, C.c_uint64, vp, vp, vp]
     L.edtts_sample_inpaint.argtypes = [C.POINTER(EdttsDims), vp, vp, vp, i32, i32, i32, vp, vp, vp, i32, vp, vp, C.POINTER(f32), vp, i32,
                                        vp, C.c_uint64, f32, vp, vp]
     L.edtts_sample_multistep.argtypes = [C.POINTER(EdttsDims), vp, vp, i32, i32, i32, vp, vp, vp, i32, C.POINTER(C.c_int64),

@@ -208,6 +208,27 @@ int edtts_dsconv_forward(const float* x, const float* dw, const float* pw, const
                          const float* gn_b, int B, int C_in, int C_out, int T, int ksize, int groups,
                          float* scratch, float* y, void* stream);
 
+/* ---- mel post-processing  (the step after the sampler in the reference's scripts: generate_sample.py:115-145,
+ * inference_pipeline.py:382-396) -----------------------------------------------------------------
+ * edtts_mel_to_spec: with mean/std [B,n_mels]: denormalize_mel (utils/audio.py:17-19: mel_n * std + mean) -> exp ->; with both
+ * NULL the input already is the linear mel spectrogram ->
+ * torchaudio.transforms.InverseMelScale (driver "gelsd": the minimum-norm least-squares solution, i.e. multiplication by the
+ * pseudo-inverse `pinv` [n_freqs,n_mels] of the transposed mel filter bank, computed once by the host) -> relu.
+ * mel_n [B,T,n_mels] -> spec [B,n_freqs,T] (the reference's / torch's layout, power spectrogram).
+ * edtts_griffin_lim: torchaudio.functional.griffinlim(rand_init=True, length=None): magnitude = spec^(1/power); n_iter times
+ * {istft -> stft(center, reflect) -> angles = (rebuilt - m*prev) / (|.| + 1e-16), m = momentum/(1+momentum)}; final istft.
+ * window [n_fft] (hann, win_length = n_fft); twiddle [n_fft/2][2] = exp(-2 pi i q / n_fft) (host table, fp64-evaluated);
+ * angles0 [B,n_freqs,T,2] = the complex torch.rand draw the reference starts from (parity runs inject it) or NULL -> hashed
+ * uniforms keyed by (seed, element).  scratch: edtts_griffin_lim_scratch_floats floats.  wave_out [B, hop*(T-1)].
+ * Compiled for n_fft = 1024 (CFG.n_fft).  PARITY UNPINNED for these two entry points: the reference calls torchaudio, which
+ * cannot be installed offline; the oracle restates torchaudio's published algorithm on torch.stft / torch.istft. */
+int edtts_mel_to_spec(const float* mel_n, const float* mean, const float* stdv, const float* pinv, int B, int T, int n_mels,
+                      int n_freqs, float* spec, void* stream);
+int edtts_griffin_lim_scratch_floats(int B, int T, int n_fft, int hop, size_t* out_floats);
+int edtts_griffin_lim(const float* spec, int B, int T, int n_fft, int hop, const float* window, const float* twiddle, int n_iter,
+                      float momentum, float power, const float* angles0, uint64_t seed, float* scratch, float* wave_out,
+                      void* stream);
+
 /* ---- measurement hook (bench.py roofline leg) -----------------------------------------------------------
  * edtts_profile_enable(n > 0): from now on every transformer-layer kernel launch is bracketed by a pair of
  * hipEvents recorded on the stream it is launched on, up to n launches; n = 0 disables and releases the events.

@@ -418,3 +418,62 @@ def inpaint_teacher_refine(sd: SD, tabs, x_coarse, sem_features, noise, known_me
     t_start = int(T * strength)
     x = tabs["sqrt_alpha_bar"][t_start] * x_coarse + tabs["sqrt_one_minus_alpha_bar"][t_start] * noise
     return inpaint_loop(sd, tabs, x, sem_features, linspace_times(t_start, steps), 0, known_mel, overlap_len, noise_k, cfg_scale, **kw)
+
+
+# ------------------------------------------------------------------------------------------------
+# mel post-processing: denormalise -> exp -> InverseMelScale -> Griffin-Lim
+#
+# PARITY UNPINNED for this section: the reference calls torchaudio (generate_sample.py:115-145, inference_pipeline.py:382-396),
+# which is not installed in the build container and cannot be fetched, so no golden vector of the reference exists.  What follows
+# restates torchaudio's published algorithms (torchaudio 2.x: functional.melscale_fbanks, transforms.InverseMelScale (driver
+# "gelsd"), functional.griffinlim) on top of torch.stft / torch.istft -- the same primitives torchaudio itself calls.
+# ------------------------------------------------------------------------------------------------
+def melscale_fbanks(n_freqs: int, f_min: float, f_max: float, n_mels: int, sample_rate: int) -> Tensor:
+    """torchaudio.functional.melscale_fbanks(norm=None, mel_scale="htk"): triangular filters [n_freqs, n_mels]."""
+    all_freqs = torch.linspace(0, sample_rate // 2, n_freqs)
+    m_min = 2595.0 * math.log10(1.0 + f_min / 700.0)
+    m_max = 2595.0 * math.log10(1.0 + f_max / 700.0)
+    m_pts = torch.linspace(m_min, m_max, n_mels + 2)
+    f_pts = 700.0 * (10 ** (m_pts / 2595.0) - 1.0)
+    f_diff = f_pts[1:] - f_pts[:-1]
+    slopes = f_pts.unsqueeze(0) - all_freqs.unsqueeze(1)
+    down = (-1.0 * slopes[:, :-2]) / f_diff[:-1]
+    up = slopes[:, 2:] / f_diff[1:]
+    return torch.max(torch.zeros(1), torch.min(down, up))
+
+
+def inverse_mel_scale(melspec: Tensor, fb: Tensor) -> Tensor:
+    """torchaudio.transforms.InverseMelScale.forward: relu(lstsq(fb^T, melspec).solution) with the minimum-norm driver "gelsd";
+    melspec [B, n_mels, T] -> [B, n_freqs, T]."""
+    sol = torch.linalg.lstsq(fb.transpose(-1, -2)[None].to(melspec.dtype), melspec, driver="gelsd").solution
+    return torch.relu(sol)
+
+
+def griffin_lim(specgram: Tensor, n_fft: int, hop: int, win_length: int, n_iter: int, power: float = 2.0, momentum: float = 0.99,
+                angles0: Optional[Tensor] = None) -> Tensor:
+    """torchaudio.functional.griffinlim (rand_init=True, length=None): specgram [B, n_freqs, T] (power spectrogram) -> waveform
+    [B, hop * (T - 1)].  angles0: the complex torch.rand draw (uniform real and imaginary parts) the reference takes first."""
+    window = torch.hann_window(win_length, dtype=specgram.dtype)
+    mom = momentum / (1 + momentum)
+    mag = specgram.pow(1 / power)
+    angles = angles0 if angles0 is not None else torch.rand(mag.shape, dtype=torch.complex64 if mag.dtype == torch.float32 else torch.complex128)
+    tprev = torch.tensor(0.0, dtype=mag.dtype)
+    for _ in range(n_iter):
+        inverse = torch.istft(mag * angles, n_fft=n_fft, hop_length=hop, win_length=win_length, window=window)
+        rebuilt = torch.stft(inverse, n_fft=n_fft, hop_length=hop, win_length=win_length, window=window, center=True, pad_mode="reflect",
+                             normalized=False, onesided=True, return_complex=True)
+        angles = rebuilt
+        if mom:
+            angles = angles - tprev * mom
+        angles = angles / (angles.abs() + 1e-16)
+        tprev = rebuilt
+    return torch.istft(mag * angles, n_fft=n_fft, hop_length=hop, win_length=win_length, window=window)
+
+
+def mel_to_waveform(mel_n: Tensor, mean: Tensor, std: Tensor, fb: Tensor, n_fft: int, hop: int, win_length: int, n_iter: int = 32,
+                    angles0: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
+    """generate_sample.py:115-145: denormalize_mel (utils/audio.py:17-19) -> exp -> transpose -> InverseMelScale -> GriffinLim.
+    mel_n [B, T, n_mels]; mean / std [B, 1, n_mels].  Returns (linear power spectrogram [B, n_freqs, T], waveform)."""
+    lin_mel = torch.exp(mel_n * std + mean).transpose(1, 2)
+    spec = inverse_mel_scale(lin_mel, fb)
+    return spec, griffin_lim(spec, n_fft, hop, win_length, n_iter, angles0=angles0)
