@@ -49,7 +49,8 @@ struct Cfg16 {
   // exactly PH = HT fragments (1 KiB each) -- one PHASE.  The block shares one LDS ring of NS phase slots (see LdsRing).
   static constexpr int PH = HT;                 // fragments per phase
   static constexpr int NS = 6;                  // ring slots (phases): NS - 1 phases are in flight ahead of the consumers
-  static constexpr int LDS_BYTES = NS * PH * 1024;
+  static constexpr int PARAM_FLOATS = 4 * H + MEL;  // FFN up bias (stream order) + out_proj bias, staged in LDS (see k_layer16)
+  static constexpr int LDS_BYTES = NS * PH * 1024 + PARAM_FLOATS * 4;
   static_assert(DH == 32, "the bf16 instance is built for head_dim 32 (one MFMA k-tile per head)");
   static_assert(H % 64 == 0 && MEL % 16 == 0 && PH % WAVES == 0 && LDS_BYTES <= 160 * 1024, "dims vs ring");
 };
@@ -104,8 +105,12 @@ struct LdsRing {
     static_assert(SHARE * (NS - 2) <= 63, "vmcnt immediate");
     // all but the SHARE * (NS - 2) youngest vector-memory operations done => the DMAs of phase `next` (and everything older) landed
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SHARE * (NS - 2)) : "memory");
+#ifndef EDTTS16_ABLATE_BARRIER  // timing ablations only (results wrong by construction)
     __builtin_amdgcn_s_barrier();
+#endif
+#ifndef EDTTS16_ABLATE_DMA
     issue(next + NS - 1);
+#endif
     const f4* p = lds + (next % NS) * PH * 64 + lane;
     ++next;
     return p;
@@ -120,9 +125,17 @@ template <int KT, bool SWAP, class C>
 EDTTS_DEV void gemm16_pair(LdsRing<C>& ring, const bf8 (&in)[KT][2], f4 (&a)[2], f4 (&b)[2]) {
   static_assert(2 * KT == C::PH, "an n-tile pair over all k-tiles is one phase");
   const f4* fr = ring.acquire();
+  // all fragments of the phase are requested from LDS up front (in-order returns: the MFMAs wait with a counted lgkmcnt each),
+  // instead of read / wait / use per fragment pair, which exposes the LDS latency KT times per phase.  (Requesting the NEXT
+  // phase's fragments right after this phase's MFMAs -- to take the barrier and the LDS round trip off the critical path -- was
+  // measured 18 % slower: the 64 registers held across the phase boundary bring the spills back.)
+  f4 fg[2 * KT];
+#pragma unroll
+  for (int i = 0; i < 2 * KT; ++i) fg[i] = fr[i * 64];
+  __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int kt = 0; kt < KT; ++kt) {
-    const bf8 fa = as_bf8(fr[(2 * kt) * 64]), fb = as_bf8(fr[(2 * kt + 1) * 64]);
+    const bf8 fa = as_bf8(fg[2 * kt]), fb = as_bf8(fg[2 * kt + 1]);
 #pragma unroll
     for (int ft = 0; ft < 2; ++ft) {
       a[ft] = SWAP ? EDTTS_MFMA16(in[kt][ft], fa, a[ft]) : EDTTS_MFMA16(fa, in[kt][ft], a[ft]);
@@ -135,9 +148,13 @@ template <int NT, class C>
 EDTTS_DEV void ktile16(LdsRing<C>& ring, const bf8 (&in)[2], f4 (&acc)[NT][2]) {
   static_assert(NT == C::PH, "one k-tile over all n-tiles is one phase");
   const f4* fr = ring.acquire();
+  f4 fg[NT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i) fg[i] = fr[i * 64];
+  __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
-    const bf8 fa = as_bf8(fr[nt * 64]);
+    const bf8 fa = as_bf8(fg[nt]);
     acc[nt][0] = EDTTS_MFMA16(fa, in[0], acc[nt][0]);
     acc[nt][1] = EDTTS_MFMA16(fa, in[1], acc[nt][1]);
   }
@@ -502,32 +519,32 @@ __global__ __launch_bounds__(C::THREADS) void k_layer16(KArgs a) {
   const size_t rowbase = (size_t)b * a.Tp + m0 + fq;
   Ring16<C> ring;
   ring.start(a.stream, ring_lds16, __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane);
+  // Small parameter vectors that are read INSIDE the streaming loops go through LDS: an ordinary global load consumed while
+  // ring DMAs are in flight makes hipcc's waitcnt pass emit s_waitcnt vmcnt(0) (it cannot count the DMAs of earlier loop
+  // iterations), which drains the whole prefetch ring once per phase -- measured: 2 800 cycles per 512-cycle phase.
+  float* const params = reinterpret_cast<float*>(ring_lds16 + C::NS * C::PH * 64);
+  for (int i = threadIdx.x; i < 4 * C::H; i += C::THREADS) params[i] = a.up_b[i];
+  if (TAIL != TAIL_QKV)
+    for (int i = threadIdx.x; i < C::MEL; i += C::THREADS) params[4 * C::H + i] = a.outp_b[i];
+  __syncthreads();
 
-  // residual tile (fp32) and the branch accumulator (see k_layer: a branch is added to the residual once, at its end)
-  f4 h[C::HT][2], delta[C::HT][2];
+  // residual tile (fp32).  Unlike the fp32 kernel, the branches accumulate straight into it: the rounding of the partial sums at
+  // the residual's magnitude (~1e-6) is three orders below the bf16 operand rounding, and a separate branch tile would cost 128
+  // more registers (measured: spills, whose scratch reloads force s_waitcnt vmcnt(0) and drain the weight ring).
+  f4 h[C::HT][2];
   float* const hp = a.h + rowbase * C::H + 4 * g;
 #pragma unroll
   for (int nt = 0; nt < C::HT; ++nt) {
     const f4 pb = ldg4(a.proj_b + 16 * nt + 4 * g);
 #pragma unroll
-    for (int ft = 0; ft < 2; ++ft) {
-      h[nt][ft] = ldg4(hp + 16 * nt + (size_t)ft * 16 * C::H);
-      delta[nt][ft] = pb;
-    }
+    for (int ft = 0; ft < 2; ++ft) h[nt][ft] = ldg4(hp + 16 * nt + (size_t)ft * 16 * C::H) + pb;
   }
-  auto add_delta = [&]() {
-#pragma unroll
-    for (int nt = 0; nt < C::HT; ++nt)
-#pragma unroll
-      for (int ft = 0; ft < 2; ++ft) h[nt][ft] += delta[nt][ft];
-  };
   // ---- x = x + attn(norm1(x, cond))   (transformer.py:142-146; q / k / v^T were produced by the previous kernel) ----
   {
     const __bf16* qrow = reinterpret_cast<const __bf16*>(a.q) + rowbase * C::H + 8 * g;
     auto qf = [&](int hd, int ft) { return *reinterpret_cast<const bf8*>(qrow + (size_t)ft * 16 * C::H + hd * C::DH); };
     attention16<C, true>(qf, reinterpret_cast<const __bf16*>(a.k) + (size_t)b * a.Tp * C::H,
-                         reinterpret_cast<const __bf16*>(a.vT) + (size_t)b * C::H * a.Tp, a.Tp, a.T, a.window, m0, lane, ring, delta);
-    add_delta();
+                         reinterpret_cast<const __bf16*>(a.vT) + (size_t)b * C::H * a.Tp, a.Tp, a.T, a.window, m0, lane, ring, h);
   }
   // ---- x = x + cross_attn(norm2(x), context)   (transformer.py:151, mla.py:118-194) ----
   {
@@ -547,8 +564,6 @@ __global__ __launch_bounds__(C::THREADS) void k_layer16(KArgs a) {
           }
       }
     }
-#pragma unroll
-    for (int nt = 0; nt < C::HT; ++nt) delta[nt][0] = delta[nt][1] = splat(0.f);
     auto qf = [&](int hd, int ft) {
       bf8 r = qx[0][ft];
 #pragma unroll
@@ -557,23 +572,26 @@ __global__ __launch_bounds__(C::THREADS) void k_layer16(KArgs a) {
       return r;
     };
     attention16<C, false>(qf, reinterpret_cast<const __bf16*>(a.kc) + (size_t)b * a.Sp * C::H,
-                          reinterpret_cast<const __bf16*>(a.vcT) + (size_t)b * C::H * a.Sp, a.Sp, a.S, -1, m0, lane, ring, delta);
-    add_delta();
+                          reinterpret_cast<const __bf16*>(a.vcT) + (size_t)b * C::H * a.Sp, a.Sp, a.S, -1, m0, lane, ring, h);
   }
   // ---- x = x + ffn(norm3(x, cond))   (transformer.py:154-158, :13-49) ----
   {
     bf8 hn[C::KT][2];
     rms_norm_pack<C>(h, a.n3w, a.cond + (size_t)b * a.cond_bstride + ((size_t)a.layer * 2 + 1) * 2 * C::H, g, hn);
 #pragma unroll
-    for (int nt = 0; nt < C::HT; ++nt) delta[nt][0] = delta[nt][1] = ldg4(a.down_b + 16 * nt + 4 * g);
+    for (int nt = 0; nt < C::HT; ++nt) {
+      const f4 db = ldg4(a.down_b + 16 * nt + 4 * g);
+      h[nt][0] += db;
+      h[nt][1] += db;
+    }
     for (int jp = 0; jp < C::HT; ++jp) {  // 2H hidden features = HT k-tiles of the down projection
       f4 act[2][2];
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const int j = 2 * jp + u;
-        const f4 vb = ldg4(a.up_b + 32 * j + 4 * g), gb = ldg4(a.up_b + 32 * j + 16 + 4 * g);
         f4 v[2] = {splat(0.f), splat(0.f)}, gt[2] = {splat(0.f), splat(0.f)};
         gemm16_pair<C::KT, false>(ring, hn, v, gt);
+        const f4 vb = *reinterpret_cast<const f4*>(params + 32 * j + 4 * g), gb = *reinterpret_cast<const f4*>(params + 32 * j + 16 + 4 * g);
 #pragma unroll
         for (int ft = 0; ft < 2; ++ft) {
           v[ft] += vb;
@@ -586,9 +604,8 @@ __global__ __launch_bounds__(C::THREADS) void k_layer16(KArgs a) {
         }
       }
       const bf8 ab[2] = {pack8(act[0][0], act[1][0]), pack8(act[0][1], act[1][1])};
-      ktile16<C::HT>(ring, ab, delta);
+      ktile16<C::HT>(ring, ab, h);
     }
-    add_delta();
   }
   // ---- tail ----
   if (TAIL == TAIL_QKV) {
@@ -611,7 +628,7 @@ __global__ __launch_bounds__(C::THREADS) void k_layer16(KArgs a) {
       for (int u = 0; u < 2; ++u) {
         const int nt = 2 * p + u;
         if (nt >= C::MT) continue;  // the padding half of the last pair
-        const f4 ob = ldg4(a.outp_b + 16 * nt + 4 * g);
+        const f4 ob = *reinterpret_cast<const f4*>(params + 4 * C::H + 16 * nt + 4 * g);
 #pragma unroll
         for (int ft = 0; ft < 2; ++ft) {
           const int f = m0 + 16 * ft + fq;

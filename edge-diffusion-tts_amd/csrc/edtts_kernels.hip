@@ -158,7 +158,7 @@ static int make_layout(const EdttsDims* d, Layout* lo) {
       o = y.s_ffn + HT * (4 * KT + HT) * kFrag;  // per down k-tile: up value/gate of its two hidden tiles, then the down fragments
     }
     lo->s_outp = o; o += MTP * 2 * KT * kFrag;  // final out_proj as n-tile pairs (the last pair may be half empty)
-    o += 8 * HT * kFrag;  // the LDS ring prefetches NS - 1 phases (of HT fragments) past the last consumed one
+    o += 8 * HT * kFrag;  // the LDS ring prefetches NS phases (of HT fragments) past the last consumed one
   } else {
   lo->inp = o; o += HT * MT * kFrag;  // in_proj, n-tile pairs: the prologue kernel streams inp | qkv(0)
   for (int l = 0; l < lo->L; ++l) {
