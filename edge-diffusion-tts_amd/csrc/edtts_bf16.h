@@ -432,14 +432,16 @@ EDTTS_DEV void qkv_tail16(Ring16<C>& ring, const bf8 (&hn)[C::KT][2], const KArg
     for (int p = 0; p < C::KT; ++p) {
       f4 acc[2][2] = {{splat(0.f), splat(0.f)}, {splat(0.f), splat(0.f)}};
       gemm16_pair<C::KT, false>(ring, hn, acc[0], acc[1]);
-      // q: row-major [frame][H] (read back by this wave only); k: tile-contiguous image [head p][key tile][16 keys][32 slots]
+      // q: row-major [frame][H] (read back by this wave only); k: tile-contiguous image [head p][key tile][16 keys][32 slots].
+      // PLAIN stores, not streaming ones: on gfx9 stores retire through the same in-order vmcnt as the ring's DMAs, and a
+      // nontemporal store takes microseconds to be acknowledged -- scratch/ring_probe.cpp: 9 060 vs 1 920 cycles per phase
       __bf16* dst = which == 0 ? qo + rowbase * C::H + 32 * p + 8 * g
                                : ko + ((size_t)(b * C::HEADS + p) * (a.Tp >> 4) + (m0 >> 4)) * 512 + fq * 32 + 8 * g;
       const size_t fstride = which == 0 ? (size_t)16 * C::H : 512;
       if (valid)
 #pragma unroll
       for (int ft = 0; ft < 2; ++ft)
-        __builtin_nontemporal_store(as_f4(pack8(acc[0][ft], acc[1][ft])), reinterpret_cast<f4*>(dst + ft * fstride));
+        *reinterpret_cast<f4*>(dst + ft * fstride) = as_f4(pack8(acc[0][ft], acc[1][ft]));
     }
   }
   for (int p = 0; p < C::KT; ++p) {
@@ -449,7 +451,7 @@ EDTTS_DEV void qkv_tail16(Ring16<C>& ring, const bf8 (&hn)[C::KT][2], const KArg
     for (int u = 0; u < 2; ++u) {
       // v^T image: [head p][32-key chunk][d-tile u][16 d][32 key slots]
       __bf16* dst = vo + ((size_t)(b * C::HEADS + p) * (a.Tp >> 5) + (m0 >> 5)) * 1024 + u * 512 + fq * 32 + 8 * g;
-      if (valid) __builtin_nontemporal_store(as_f4(pack8(acc[u][0], acc[u][1])), reinterpret_cast<f4*>(dst));
+      if (valid) *reinterpret_cast<f4*>(dst) = as_f4(pack8(acc[u][0], acc[u][1]));
     }
   }
 }

@@ -44,12 +44,11 @@ struct Cfg {
   static constexpr int MT = MEL / 16;             // feature tiles of the mel dim
   static constexpr int R = H / 2, RT = R / 16;    // kv_lora_rank (transformer.py:113) and its tiles
   static constexpr int VR = (HEADS - 1) * DH + DHP;  // rows of a V^T buffer (last head padded)
-  static constexpr int WAVES = H > 192 ? (NF == 2 ? 2 : 1) : 4;  // waves per block (bounded by the LDS q tiles)
-  // LDS row stride (floats) of the cross-attention q tile: padded by 4 when it fits, unpadded when 4 waves x WF rows
-  // would otherwise exceed the 160 KiB of the CU
-  static constexpr int QLD = (WAVES * WF * (H + 4) * 4 <= 160 * 1024) ? H + 4 : H;
+  static constexpr int WAVES = (HT * NF * 4 <= 160) ? 4 : 2;  // waves per block (each parks its residual tile, HT*NF KiB, in LDS)
+  // the cross-attention q tile goes through LDS when it fits next to the parked residual tiles (160 KiB per block at H = 160,
+  // NF = 2), else through this wave's (already consumed) self-attention q rows in global memory
+  static constexpr bool Q_IN_LDS = WAVES * WF * H * 4 * 2 <= 160 * 1024;
   static constexpr int THREADS = 64 * WAVES;
-  static_assert(WAVES * WF * QLD * 4 <= 160 * 1024, "q tiles exceed LDS");
   static_assert(NF == 2 || NF == 4, "frame tiles per wave");
   static_assert(H % 32 == 0 && MEL % 16 == 0 && H % HEADS == 0, "dims");
   static_assert(DREM == 0 || DREM == 8, "head_dim % 16 must be 0 or 8");

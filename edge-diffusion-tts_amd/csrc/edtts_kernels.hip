@@ -639,12 +639,10 @@ enum { PART_ALL = 0, PART_ATTN = 1, PART_FFN = 2 };
 #define EDTTS_GCLUMP 1
 #endif
 // Where the residual tile waits while a branch accumulates (measured on one MI355X, B=256, T=512, whole generate_mel call):
-//   2 (default): in LDS, next to the (unpadded) cross-attention q tiles -- 160 KiB per block at H = 160       16.42 ms
-//   1: in LDS, with the cross-attention q rows going through global memory (this wave's dead self-attention q rows) 16.53 ms
-//   0: in the wave's own rows of the h buffer (global), q tiles padded in LDS                                      16.6 ms
-#ifndef EDTTS_HSTASH
-#define EDTTS_HSTASH 2
-#endif
+//   in LDS, next to the (unpadded) cross-attention q tiles -- 160 KiB per block at H = 160 (Cfg::Q_IN_LDS)           16.42 ms
+//   in LDS, with the cross-attention q rows going through global memory (this wave's dead self-attention q rows)     16.53 ms
+//   in the wave's own rows of the h buffer (global), q tiles padded in LDS                                           16.6 ms
+// The first form is used where it fits, the second otherwise (hidden 256: four waves x 32 KiB of residual tiles).
 template <class C, int TAIL, int PART>
 __global__ __launch_bounds__(C::THREADS) void k_layer(KArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -654,18 +652,11 @@ __global__ __launch_bounds__(C::THREADS) void k_layer(KArgs a) {
   const int lane = threadIdx.x & 63, fq = lane & 15, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int b = tl.b, m0 = tl.m0;
-#if EDTTS_HSTASH
   // this wave's parking place for the residual tile, in REGISTER layout (element [nt][ft] of lane l at ((nt*NF + ft)*64 + l) * 16 B:
   // conflict-free b128 accesses, no padding)
   f4* const stash = reinterpret_cast<f4*>(smem) + (size_t)wave * C::HT * NF * 64 + lane;
-#endif
-#if EDTTS_HSTASH == 2
   constexpr int QLDS = C::H;  // q rows unpadded: stash + q tiles fill the CU's 160 KiB exactly at H = 160 (q is read a few times per head)
-  float* qtile = smem + (size_t)C::WAVES * C::HT * NF * 256 + (size_t)wave * C::WF * QLDS;
-#elif EDTTS_HSTASH == 0
-  constexpr int QLDS = C::QLD;
-  float* qtile = smem + (size_t)wave * C::WF * C::QLD;
-#endif
+  float* qtile = smem + (size_t)C::WAVES * C::HT * NF * 256 + (size_t)wave * C::WF * QLDS;  // (only touched when C::Q_IN_LDS)
   const size_t rowbase = (size_t)b * a.Tp + m0 + fq;
 
   WStream<C> ring;
@@ -677,10 +668,9 @@ __global__ __launch_bounds__(C::THREADS) void k_layer(KArgs a) {
   // sum at the residual's magnitude (|h| ~ 2..8, ulp 2.4e-7 .. 4.8e-7) instead of the branch's (~0.1..1): measured on MI355X, that
   // alone put the decoder's error vs the fp64 arbiter at 3.8e-6 max (the reference's own fp32: 1.1e-6); with the branches apart it
   // is 1.0e-6 max / 1.9e-7 rms, i.e. at the reference's level.  While a branch accumulates, the residual tile is parked (see
-  // EDTTS_HSTASH) rather than held in 16*NF*HT more registers.
+  // the note above the kernel) rather than held in 16*NF*HT more registers.
   f4 h[C::HT][NF];
   float* const hp = a.h + rowbase * C::H + 4 * g;
-#if EDTTS_HSTASH
   auto park_h = [&]() {
 #pragma unroll
     for (int nt = 0; nt < C::HT; ++nt)
@@ -693,20 +683,6 @@ __global__ __launch_bounds__(C::THREADS) void k_layer(KArgs a) {
 #pragma unroll
       for (int ft = 0; ft < NF; ++ft) h[nt][ft] += stash[(nt * NF + ft) * 64];
   };
-#else
-  auto park_h = [&]() {  // (padding waves have returned)
-#pragma unroll
-    for (int nt = 0; nt < C::HT; ++nt)
-#pragma unroll
-      for (int ft = 0; ft < NF; ++ft) stg4(hp + 16 * nt + (size_t)ft * 16 * C::H, h[nt][ft]);
-  };
-  auto add_parked_h = [&]() {  // h (the finished branch) += residual
-#pragma unroll
-    for (int nt = 0; nt < C::HT; ++nt)
-#pragma unroll
-      for (int ft = 0; ft < NF; ++ft) h[nt][ft] += ldg4(hp + 16 * nt + (size_t)ft * 16 * C::H);
-  };
-#endif
 #ifdef EDTTS_DIAG
 #define DIAG_ON(bit) (!(a.diag_skip & (bit)))
 #else
@@ -714,14 +690,12 @@ __global__ __launch_bounds__(C::THREADS) void k_layer(KArgs a) {
 #endif
   // ---- x = x + attn(norm1(x, cond))   (transformer.py:142-146; q/k/v were produced by the previous kernel) ----
   if (PART != PART_FFN) {
-#if EDTTS_HSTASH
     // the residual goes from the h buffer straight to its parking place (the loads fly together with the first head's q / K / V^T)
 #pragma unroll
     for (int nt = 0; nt < C::HT; ++nt)
 #pragma unroll
       for (int ft = 0; ft < NF; ++ft) h[nt][ft] = ldg4(hp + 16 * nt + (size_t)ft * 16 * C::H);
     park_h();
-#endif
     // branch tile starts at the projection bias (attention.py:123); the residual itself stays parked until the branch is done
 #pragma unroll
     for (int nt = 0; nt < C::HT; ++nt) {
@@ -756,12 +730,10 @@ __global__ __launch_bounds__(C::THREADS) void k_layer(KArgs a) {
         for (int u = 0; u < 2; ++u)
 #pragma unroll
           for (int ft = 0; ft < NF; ++ft) {
-#if EDTTS_HSTASH == 1
-            // the cross-attention q rows take the place of this wave's self-attention q rows (read by this wave only, and consumed)
-            stg4(const_cast<float*>(a.q) + (rowbase + 16 * ft) * C::H + 16 * (nt + u) + 4 * g, acc[u][ft]);
-#else
-            stg4(qtile + (16 * ft + fq) * QLDS + 16 * (nt + u) + 4 * g, acc[u][ft]);
-#endif
+            // without room in LDS the cross-attention q rows take the place of this wave's self-attention q rows (read by this
+            // wave only, and consumed)
+            if (C::Q_IN_LDS) stg4(qtile + (16 * ft + fq) * QLDS + 16 * (nt + u) + 4 * g, acc[u][ft]);
+            else stg4(const_cast<float*>(a.q) + (rowbase + 16 * ft) * C::H + 16 * (nt + u) + 4 * g, acc[u][ft]);
           }
       }
     }
@@ -769,13 +741,15 @@ __global__ __launch_bounds__(C::THREADS) void k_layer(KArgs a) {
     for (int nt = 0; nt < C::HT; ++nt)
 #pragma unroll
       for (int ft = 0; ft < NF; ++ft) h[nt][ft] = splat(0.f);
-#if EDTTS_HSTASH == 1
-    QGlobal ql{a.q + rowbase * C::H, C::H};
-#else
-    QLds ql{qtile + fq * QLDS, QLDS};
-#endif
-    attention_fused<C, false>(ql, a.kc + (size_t)b * a.Sp * C::H, a.vcT + (size_t)b * C::VR * a.Sp, a.Sp, a.S, -1, m0, lane,
-                              ring, h);
+    if constexpr (C::Q_IN_LDS) {
+      QLds ql{qtile + fq * QLDS, QLDS};
+      attention_fused<C, false>(ql, a.kc + (size_t)b * a.Sp * C::H, a.vcT + (size_t)b * C::VR * a.Sp, a.Sp, a.S, -1, m0, lane,
+                                ring, h);
+    } else {
+      QGlobal ql{a.q + rowbase * C::H, C::H};
+      attention_fused<C, false>(ql, a.kc + (size_t)b * a.Sp * C::H, a.vcT + (size_t)b * C::VR * a.Sp, a.Sp, a.S, -1, m0, lane,
+                                ring, h);
+    }
     add_parked_h();
   }
   if (PART == PART_ATTN) {  // hand the residual tile to the FFN half
@@ -1273,12 +1247,8 @@ struct LmsStepArgs {
 template <class C>
 struct Launcher {
   static size_t ring_lds() { return 0; }
-#if EDTTS_HSTASH
   template <class CC> static size_t stash_lds() { return (size_t)CC::WAVES * CC::HT * CC::NF * 1024; }  // residual parking place
-  static size_t layer_lds() { return stash_lds<C>() + (EDTTS_HSTASH == 2 ? (size_t)C::WAVES * C::WF * C::H * sizeof(float) : 0); }
-#else
-  static size_t layer_lds() { return ring_lds() + (size_t)C::WAVES * C::WF * C::QLD * sizeof(float); }
-#endif
+  static size_t layer_lds() { return stash_lds<C>() + (C::Q_IN_LDS ? (size_t)C::WAVES * C::WF * C::H * sizeof(float) : 0); }
   // split layer: attention half with this instance (C), FFN + tail half with CF (more frames per wave)
   static constexpr bool SPLIT = (EDTTS_NF_FFN > C::NF) && C::H <= 192;
   using CF = Cfg<C::H, C::HEADS, C::MEL, (SPLIT ? EDTTS_NF_FFN : C::NF)>;
@@ -1367,7 +1337,7 @@ struct Launcher {
         a.c_s1m = coef[0]; a.c_sab = coef[1]; a.c_sabp = coef[2]; a.c_dir = coef[3];
       }
       if (SPLIT) {
-        static_assert(!SPLIT || !EDTTS_HSTASH, "the two-launch layer experiment is built with -DEDTTS_HSTASH=0");
+        static_assert(!SPLIT, "the two-launch layer experiment predates the LDS-parked residual tile (see git history)");
         g_prof.kind = 0;
         PROF_LAUNCH(st, hipLaunchKernelGGL((k_layer<C, TAIL_QKV, PART_ATTN>), dim3(g), dim3(C::THREADS), layer_lds(), st, a));
         LAUNCH_CHECK("k_layer<attn>");
