@@ -34,7 +34,8 @@ template <int H_, int HEADS_, int MEL_, int NF_ = 2>
 struct Cfg {
   static constexpr int H = H_, HEADS = HEADS_, MEL = MEL_, NF = NF_;
   static constexpr int WF = 16 * NF;              // frames per wave
-  static constexpr int NHALF = NF / 2;            // attention passes per wave (2 frame tiles each)
+  static constexpr int QT = NF >= 2 ? 2 : 1;      // query tiles per attention pass
+  static constexpr int NHALF = NF / QT;           // attention passes per wave (QT frame tiles each)
   static constexpr int DH = H / HEADS;            // head dim (40 for the default decoder)
   static constexpr int DFULL = DH / 16;           // full 16-wide groups of the head dim
   static constexpr int DREM = DH % 16;            // remainder (0 or 8 supported)
@@ -49,7 +50,7 @@ struct Cfg {
   // NF = 2), else through this wave's (already consumed) self-attention q rows in global memory
   static constexpr bool Q_IN_LDS = WAVES * WF * H * 4 * 2 <= 160 * 1024;
   static constexpr int THREADS = 64 * WAVES;
-  static_assert(NF == 2 || NF == 4, "frame tiles per wave");
+  static_assert(NF == 1 || NF == 2 || NF == 4, "frame tiles per wave");
   static_assert(H % 32 == 0 && MEL % 16 == 0 && H % HEADS == 0, "dims");
   static_assert(DREM == 0 || DREM == 8, "head_dim % 16 must be 0 or 8");
 };
@@ -341,6 +342,7 @@ EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, cons
                                int nkeys, int window, int m0w, int lane, WStream<C>& ring, f4 (&h)[C::HT][C::NF]) {
   constexpr int DH = C::DH, DFULL = C::DFULL, DREM = C::DREM, DT = C::DT, H = C::H, CH = kChunk, NF = C::NF;
   constexpr int NHALF = C::NHALF;
+  constexpr int QT = C::QT;  // query tiles per half: 2 (32 frames), or 1 in the small-batch instance (NF = 1)
   const int fq = lane & 15, g = lane >> 4;
   const float NEG_INF = -__builtin_inff();
   // Row map of the 8-feature remainder tile of V^T (head_dim % 16 == 8): MFMA row i = 4*gO + reg of the P V product carries
@@ -352,15 +354,19 @@ EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, cons
   struct Geo {
     int m0, kt_lo, kt_hi, nchunk, klim;
     int cdiag;  // chunk that holds the keys of this half's own frames (self-attention; 0 otherwise)
-    int lo_d[2], span[2];  // per-lane band limits on d = key - query: valid <=> (unsigned)(d - lo_d) <= span
+    int lo_d[QT], span[QT];  // per-lane band limits on d = key - query: valid <=> (unsigned)(d - lo_d) <= span
   };
   auto make_geo = [&](int half) {
     Geo q;
-    q.m0 = m0w + 32 * half;
+    q.m0 = m0w + 16 * QT * half;
+    // The chunk partition and order are those of the enclosing 32-frame pair of query tiles also when a pass covers ONE tile
+    // (small-batch instance, QT = 1): a query row then meets exactly the chunk sequence it meets in the 32-frame instances, and
+    // the two give bitwise identical results (an utterance alone == the same utterance inside a large batch).
+    const int mg = q.m0 & ~31;
     if (SELF && window >= 0) {
-      const int lo = q.m0 - window;
+      const int lo = mg - window;
       q.kt_lo = ((lo > 0 ? lo : 0) >> 4) & ~(CH - 1);  // chunk grid aligned to the 32-frame tiles (see cdiag)
-      const int hi = q.m0 + 31 + window;  // last key any query of this half may see
+      const int hi = mg + 31 + window;  // last key any query of this pair may see
       const int last = (hi < nkeys - 1 ? hi : nkeys - 1);
       q.kt_hi = (last >> 4) + 1;
     } else {
@@ -373,12 +379,12 @@ EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, cons
     // (With the band start not on a chunk boundary -- windows that are not multiples of 16 -- chunk 0 is fully masked for some
     // rows that do see later keys; a reference left at 0 there underflows every exp2 when all scores are far below zero.)
     // Only needed when the band start is not on a chunk boundary (else chunk 0 already shows a key to every row that has one).
-    const bool off_grid = SELF && window >= 0 && (q.m0 - window > (q.kt_lo << 4));
-    q.cdiag = off_grid ? ((q.m0 >> 4) - q.kt_lo) / CH : 0;
+    const bool off_grid = SELF && window >= 0 && (mg - window > (q.kt_lo << 4));
+    q.cdiag = off_grid ? ((mg >> 4) - q.kt_lo) / CH : 0;
     if (q.cdiag >= q.nchunk) q.cdiag = q.nchunk - 1;  // half entirely past the end of the utterance
     q.klim = (q.kt_hi << 4) < nkeys ? (q.kt_hi << 4) : nkeys;  // keys >= klim are never valid
 #pragma unroll
-    for (int ft = 0; ft < 2; ++ft) {
+    for (int ft = 0; ft < QT; ++ft) {
       const int qi = q.m0 + 16 * ft + fq;
       int lo = -(1 << 28), hi = q.klim - 1 - qi;
       if (SELF && window >= 0) {
@@ -430,14 +436,14 @@ EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, cons
     c = c < q.nchunk ? c : q.nchunk - 1;
     const int k0 = (q.kt_lo + c * CH) << 4, k1 = k0 + 16 * CH - 1;
     bool full = k1 < q.klim && (q.kt_lo + (c + 1) * CH) <= q.kt_hi;
-    if (SELF && window >= 0) full = full && (k1 - q.m0 <= window) && (k0 - (q.m0 + 31) >= -window);
+    if (SELF && window >= 0) full = full && (k1 - q.m0 <= window) && (k0 - (q.m0 + 16 * QT - 1) >= -window);
     return full;
   };
-  auto mask_init = [&](const Geo& q, int c, f4 (&S)[CH][2], const float (&vis)[2]) {  // vis: value of a VISIBLE position
+  auto mask_init = [&](const Geo& q, int c, f4 (&S)[CH][QT], const float (&vis)[QT]) {  // vis: value of a VISIBLE position
     c = c < q.nchunk ? c : q.nchunk - 1;
     const int k0 = (q.kt_lo + c * CH) << 4;
 #pragma unroll
-    for (int ft = 0; ft < 2; ++ft) {
+    for (int ft = 0; ft < QT; ++ft) {
       const int d0 = k0 + 4 * g - (q.m0 + 16 * ft + fq) - q.lo_d[ft];  // (key - query - lo_d) of r = 0, tile 0
       const unsigned sp = q.span[ft] >= 0 ? (unsigned)q.span[ft] : 0u;
       const int bias = q.span[ft] >= 0 ? 0 : (1 << 30);                 // nothing valid for this query
@@ -452,24 +458,23 @@ EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, cons
   // s - m and exp2 applies to them directly: m only changes on the rare rescale path, and folding it into the accumulator input
   // removes a v_sub per score from every step.  nm[ft] = -m as a scalar (edge chunks: the mask select picks it instead of 0),
   // NM[ft] = the same value as a whole accumulator tile (interior chunks).
-  auto qk = [&](auto fold_tag, const Geo& q, int c, const KVFrag<C>& f, const f4 (&qa)[2][DFULL > 0 ? DFULL : 1],
-                const f2 (&qr)[2], f4 (&S)[CH][2], const f4 (&NM)[2], const float (&nm)[2]) {
+  auto qk = [&](auto fold_tag, const Geo& q, int c, const KVFrag<C>& f, const f4 (&qa)[QT][DFULL > 0 ? DFULL : 1],
+                const f2 (&qr)[QT], f4 (&S)[CH][QT], const f4 (&NM)[QT], const float (&nm)[QT]) {
     static_assert(DFULL >= 1, "head_dim >= 16 expected");
     constexpr bool FOLD = decltype(fold_tag)::value;
     if (chunk_is_interior(q, c)) {
 #pragma unroll
-      for (int t = 0; t < CH; ++t) {
-        S[t][0] = FOLD ? EDTTS_MFMA(f.ka[t][0][0], qa[0][0][0], NM[0]) : EDTTS_MFMA(f.ka[t][0][0], qa[0][0][0], splat(0.f));
-        S[t][1] = FOLD ? EDTTS_MFMA(f.ka[t][0][0], qa[1][0][0], NM[1]) : EDTTS_MFMA(f.ka[t][0][0], qa[1][0][0], splat(0.f));
-      }
+      for (int t = 0; t < CH; ++t)
+#pragma unroll
+        for (int ft = 0; ft < QT; ++ft)
+          S[t][ft] = FOLD ? EDTTS_MFMA(f.ka[t][0][0], qa[ft][0][0], NM[ft]) : EDTTS_MFMA(f.ka[t][0][0], qa[ft][0][0], splat(0.f));
     } else {
-      const float zero[2] = {0.f, 0.f};
+      const float zero[QT] = {};
       mask_init(q, c, S, FOLD ? nm : zero);
 #pragma unroll
-      for (int t = 0; t < CH; ++t) {
-        S[t][0] = EDTTS_MFMA(f.ka[t][0][0], qa[0][0][0], S[t][0]);
-        S[t][1] = EDTTS_MFMA(f.ka[t][0][0], qa[1][0][0], S[t][1]);
-      }
+      for (int t = 0; t < CH; ++t)
+#pragma unroll
+        for (int ft = 0; ft < QT; ++ft) S[t][ft] = EDTTS_MFMA(f.ka[t][0][0], qa[ft][0][0], S[t][ft]);
     }
 #pragma unroll
     for (int a = 0; a < DFULL; ++a)
@@ -477,19 +482,17 @@ EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, cons
       for (int b = 0; b < 4; ++b) {
         if (a == 0 && b == 0) continue;
 #pragma unroll
-        for (int t = 0; t < CH; ++t) {
-          S[t][0] = EDTTS_MFMA(f.ka[t][a][b], qa[0][a][b], S[t][0]);
-          S[t][1] = EDTTS_MFMA(f.ka[t][a][b], qa[1][a][b], S[t][1]);
-        }
+        for (int t = 0; t < CH; ++t)
+#pragma unroll
+          for (int ft = 0; ft < QT; ++ft) S[t][ft] = EDTTS_MFMA(f.ka[t][a][b], qa[ft][a][b], S[t][ft]);
       }
     if (DREM) {
 #pragma unroll
       for (int b = 0; b < 2; ++b)
 #pragma unroll
-        for (int t = 0; t < CH; ++t) {
-          S[t][0] = EDTTS_MFMA(f.kr[t][b], qr[0][b], S[t][0]);
-          S[t][1] = EDTTS_MFMA(f.kr[t][b], qr[1][b], S[t][1]);
-        }
+        for (int t = 0; t < CH; ++t)
+#pragma unroll
+          for (int ft = 0; ft < QT; ++ft) S[t][ft] = EDTTS_MFMA(f.kr[t][b], qr[ft][b], S[t][ft]);
     }
   };
 
@@ -500,8 +503,8 @@ EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, cons
   // q fragments (B operand: lane (fq,g) holds q[query][hd*DH + 16a + 4g + b]) and the K / V^T fragments of the first
   // chunks of a (head, half).  For half 0 they are fetched while the PREVIOUS head's projection phases run, so no head
   // starts on an exposed load.
-  f4 qa_n[2][DFULL > 0 ? DFULL : 1];
-  f2 qr_n[2];
+  f4 qa_n[QT][DFULL > 0 ? DFULL : 1];
+  f2 qr_n[QT];
   KVFrag<C> KA;
   VFrag<C> VA;
 #if EDTTS_KV2
@@ -514,10 +517,10 @@ EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, cons
   };
   auto prefetch = [&](const Geo& q, int hd, int half) {
 #pragma unroll
-    for (int ft = 0; ft < 2; ++ft) {
+    for (int ft = 0; ft < QT; ++ft) {
 #pragma unroll
-      for (int a = 0; a < DFULL; ++a) qa_n[ft][a] = qload.q4(2 * half + ft, hd * DH + 16 * a + 4 * g);
-      if (DREM) qr_n[ft] = qload.q2(2 * half + ft, hd * DH + 16 * DFULL + 2 * g);
+      for (int a = 0; a < DFULL; ++a) qa_n[ft][a] = qload.q4(QT * half + ft, hd * DH + 16 * a + 4 * g);
+      if (DREM) qr_n[ft] = qload.q2(QT * half + ft, hd * DH + 16 * DFULL + 2 * g);
     }
     load_k(q, hd, q.cdiag, KA);  // the first step processes the diagonal chunk
     load_v(q, hd, q.cdiag, VA);
@@ -539,9 +542,13 @@ EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, cons
       // out of the MFMA in the exp2 domain, and the prefetched fragments are used as they are)
       const auto& qa = qa_n;
       const auto& qr = qr_n;
-      f4 lvec[2] = {splat(0.f), splat(0.f)};  // per-lane partial row sums (reduced over r and the lane groups at the end)
+      f4 lvec[QT];  // per-lane partial row sums (reduced over r and the lane groups at the end)
 #pragma unroll
-      for (int dt = 0; dt < DT; ++dt) O[dt][2 * hf] = O[dt][2 * hf + 1] = splat(0.f);
+      for (int ft = 0; ft < QT; ++ft) lvec[ft] = splat(0.f);
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int ft = 0; ft < QT; ++ft) O[dt][QT * hf + ft] = splat(0.f);
       const int nchunk = q.nchunk;
 
       // Strictly serial step, single S / K / V^T buffers:  K Q^T(c) | softmax(c) | P V(c).  Nothing overlaps an fp32 MFMA on this
@@ -555,9 +562,14 @@ EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, cons
       // step on the scores come out of the MFMAs as s - m (see qk) and the wave-uniform rescale branch is taken only when some
       // row jumps by more than kDefer octaves -- the read-modify-write of O, the cross-lane max and the subtraction of m stay
       // out of the common path.  (Chunk order: see Geo::cdiag.)
-      f4 S[CH][2];
-      f4 NM[2] = {splat(0.f), splat(0.f)};
-      float nm[2] = {0.f, 0.f};
+      f4 S[CH][QT];
+      f4 NM[QT];
+      float nm[QT];
+#pragma unroll
+      for (int ft = 0; ft < QT; ++ft) {
+        NM[ft] = splat(0.f);
+        nm[ft] = 0.f;
+      }
       using Yes = std::integral_constant<bool, true>;
       using No = std::integral_constant<bool, false>;
       auto step = [&](auto fold_tag, int c, int cnext, KVFrag<C>& KA, VFrag<C>& VA) {  // c: this step's chunk, cnext: the chunk to request into the buffers
@@ -570,11 +582,11 @@ EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, cons
         __builtin_amdgcn_sched_barrier(0);
         // one VGPR copy of the scores serves exp2 and the rare rescale (the pin keeps hipcc from re-reading the accumulators
         // after the branch)
-        f4 sv[CH][2];
+        f4 sv[CH][QT];
 #pragma unroll
         for (int t = 0; t < CH; ++t)
 #pragma unroll
-          for (int ft = 0; ft < 2; ++ft) {
+          for (int ft = 0; ft < QT; ++ft) {
             sv[t][ft] = S[t][ft];
             asm volatile("" : "+v"(sv[t][ft]));
           }
@@ -586,7 +598,7 @@ EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, cons
             for (int r = 0; r < 4; ++r) mv[r] = fmaxf(mv[r], sv[t][ft][r]);
           return hmax(mv);
         };
-        f4 P[CH][2], ps[2];  // ps: this chunk's partial row sums (per lane)
+        f4 P[CH][QT], ps[QT];  // ps: this chunk's partial row sums (per lane)
         auto exp_and_sum = [&](int ft, float m) {
 #pragma unroll
           for (int t = 0; t < CH; ++t)
@@ -599,7 +611,7 @@ EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, cons
         if (!FOLD) {
           // first chunk: the reference point is this chunk's row maximum (0 for a row without any visible key: stays finite)
 #pragma unroll
-          for (int ft = 0; ft < 2; ++ft) {
+          for (int ft = 0; ft < QT; ++ft) {
             const float gm = group_max(lane_max(ft));  // identical on the 4 lanes of a row
             const float m = gm > -1e30f ? gm : 0.f;
             nm[ft] = -m;
@@ -612,13 +624,17 @@ EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, cons
           // which are needed anyway: sum(P) > 2^kDefer (or not finite) <=> some score may exceed m by more than kDefer octaves
           // (no false negatives: sum >= max; a false positive only moves the reference early).  The per-lane maximum, the
           // cross-lane max and the read-modify-write of O then stay out of the common path entirely.
-          exp_and_sum(0, 0.f);
-          exp_and_sum(1, 0.f);
           const float lim = 4294967296.f;  // 2^kDefer
           static_assert(kDefer == 32.f, "lim above is 2^kDefer");
-          if (__any(!(hsum(ps[0]) <= lim) || !(hsum(ps[1]) <= lim))) {
+          bool over = false;
 #pragma unroll
-            for (int ft = 0; ft < 2; ++ft) {
+          for (int ft = 0; ft < QT; ++ft) {
+            exp_and_sum(ft, 0.f);
+            over = over || !(hsum(ps[ft]) <= lim);
+          }
+          if (__any(over)) {
+#pragma unroll
+            for (int ft = 0; ft < QT; ++ft) {
               const float delta = fmaxf(0.f, group_max(lane_max(ft)));  // rows that did not jump keep their reference
               const float alpha = fast_exp2(-delta);
               nm[ft] -= delta;
@@ -626,23 +642,22 @@ EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, cons
               asm volatile("" : "+a"(NM[ft]));
               lvec[ft] *= alpha;
 #pragma unroll
-              for (int dt = 0; dt < DT; ++dt) scale_acc(O[dt][2 * hf + ft], alpha);
+              for (int dt = 0; dt < DT; ++dt) scale_acc(O[dt][QT * hf + ft], alpha);
               exp_and_sum(ft, delta);
             }
           }
         }
-        lvec[0] += ps[0];
-        lvec[1] += ps[1];
+#pragma unroll
+        for (int ft = 0; ft < QT; ++ft) lvec[ft] += ps[ft];
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int t = 0; t < CH; ++t)
 #pragma unroll
           for (int r = 0; r < 4; ++r)
 #pragma unroll
-            for (int dt = 0; dt < DT; ++dt) {
-              O[dt][2 * hf] = EDTTS_MFMA(VA.v[t][dt][r], P[t][0][r], O[dt][2 * hf]);
-              O[dt][2 * hf + 1] = EDTTS_MFMA(VA.v[t][dt][r], P[t][1][r], O[dt][2 * hf + 1]);
-            }
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+              for (int ft = 0; ft < QT; ++ft) O[dt][QT * hf + ft] = EDTTS_MFMA(VA.v[t][dt][r], P[t][ft][r], O[dt][QT * hf + ft]);
         __builtin_amdgcn_sched_barrier(0);
 #ifndef EDTTS_ABLATE_KVLOADS
         load_v(q, hd, cnext, VA);
@@ -664,11 +679,11 @@ EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, cons
 #endif
       // normalise this half's rows
 #pragma unroll
-      for (int ft = 0; ft < 2; ++ft) {
+      for (int ft = 0; ft < QT; ++ft) {
         const float lt = group_sum(hsum(lvec[ft]));
         const float inv = lt > 0.f ? 1.0f / lt : 0.f;
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt) O[dt][2 * hf + ft] *= inv;
+        for (int dt = 0; dt < DT; ++dt) O[dt][QT * hf + ft] *= inv;
       }
     }
     // ---- project: h[nt] += Wo[:, head features] . O  (all NF frame tiles at once) ------------------------------------

@@ -1256,6 +1256,10 @@ struct Launcher {
   static int grid(int B, int Tp) { return (B * (Tp / C::WF) + C::WAVES - 1) / C::WAVES; }
   static int ctx_grid(int B, int Sp) { return (B * (Sp / 32) + kCtxWaves - 1) / kCtxWaves; }
   using C2 = Cfg<C::H, C::HEADS, C::MEL, 2>;  // geometry of the context kernel
+  // the 16-frames-per-wave instance for small grids (built for the default decoder)
+  static constexpr bool HAS_SMALL = C::NF == 2 && C::H == 160 && !SPLIT;
+  using Small = Cfg<C::H, C::HEADS, C::MEL, 1>;
+  static constexpr int kSmallGridBlocks = 256;  // CUs of an MI355X
 
   static int ctx(const Layout& lo, const float* blob, const Workspace& ws, float* wsb, int B, int S, const int64_t* sem_idx,
                  const float* sem_feat, hipStream_t st) {
@@ -1295,6 +1299,13 @@ struct Launcher {
                      const float* x, const float* cond_row, int cond_bstride, int tail, float* eps, float* x_prev, float* x0,
                      const float* coef, hipStream_t st, const DdpmStep* ddpm = nullptr, const LmsStep* lms = nullptr,
                      const VpredStepArgs* vp = nullptr) {
+    // Small grids: with 32 frames per wave fewer than one block per CU would be launched (B = 32 at T = 512: 128 blocks on 256
+    // CUs; B = 1: 2 blocks) -- the 16-frames-per-wave instance doubles the number of waves.  Same arithmetic per frame, bitwise.
+    if constexpr (HAS_SMALL) {
+      if (2 * grid(B, ws.Tp) <= kSmallGridBlocks)  // ... as long as the doubled grid still runs in one round
+        return Launcher<Small>::forward(lo, blob, ws, wsb, B, T, S, window, x, cond_row, cond_bstride, tail, eps, x_prev, x0, coef, st,
+                                        ddpm, lms, vp);
+    }
     KArgs a;
     base_args(lo, blob, ws, wsb, B, T, S, window, &a);
     a.x = x; a.cond = cond_row; a.cond_bstride = cond_bstride;
@@ -1380,6 +1391,10 @@ struct Launcher {
     HIP_TRY(hipGetDevice(&dev));
     if (dev < 0 || dev >= 64) return fail(EDTTS_ERR_UNSUPPORTED, "device ordinal %d out of range", dev);
     if (done[dev]) return EDTTS_OK;
+    if constexpr (HAS_SMALL) {
+      int rc = Launcher<Small>::set_attrs();
+      if (rc) return rc;
+    }
     const int lds = (int)layer_lds();
     if (SPLIT) {
       HIP_TRY(hipFuncSetAttribute((const void*)k_layer<C, TAIL_QKV, PART_ATTN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));

@@ -928,3 +928,32 @@ def test_mel_vocoder_end_to_end():
     spec_ref, wav_ref = O.mel_to_waveform(mel_n.cpu(), mean, std, fb, cfg.n_fft, cfg.hop_length, cfg.win_length, 4, angles0=a0)
     rel = float((wav - wav_ref).norm() / wav_ref.norm())
     assert wav.shape == (2, cfg.hop_length * 63) and rel < 1e-3, rel
+
+
+def test_small_batch_instance_equals_the_large_one():
+    """Small grids (fewer than one 128-frame block per two CUs) run the 16-frames-per-wave instance: same arithmetic per frame, so
+    an utterance gives bitwise the same mel whether it is sampled alone (small instance), in a batch of 32 (small instance,
+    BASELINE config 2 strong-scaled over 8 GPUs) or in a batch of 80 (32-frame instance); also for windows off the tile grid and
+    ragged lengths, and through the DDPM and multistep tails."""
+    cfg = CFG(device=DEV)
+    dec = make_decoder(cfg, 0)
+    sch = DiffusionSchedule(cfg.diff_steps).to(DEV)
+    infer = EdgeInference(cfg, sch, torch.nn.Identity(), dec)
+    gen = torch.Generator().manual_seed(40)
+    B, S = 80, 256
+    sem = torch.randint(0, 512, (B, S), generator=gen).to(DEV)
+    x = torch.randn(B, 2 * S, 80, generator=gen).to(DEV)
+    big = infer.generate_mel(sem, 4, x_T=x)                                   # 320 blocks: 32-frame instance
+    mid = infer.generate_mel(sem[:32].contiguous(), 4, x_T=x[:32].contiguous())   # 128 blocks -> 16-frame instance
+    one = infer.generate_mel(sem[7:8].contiguous(), 4, x_T=x[7:8].contiguous())
+    assert torch.equal(mid, big[:32]) and torch.equal(one[0], big[7])
+    for window, T in ((37, 150), (None, 96), (5, 70)):
+        cfgw = CFG(device=DEV, attn_window_size=window)
+        decw = make_decoder(cfgw, 2)
+        Bw = 1100 // T * 8  # enough tiles for the 32-frame instance
+        xs = torch.randn(Bw, T, 80, generator=gen).to(DEV)
+        ss = torch.randint(0, 512, (Bw, T // 2), generator=gen).to(DEV)
+        tt = torch.randint(0, 1000, (Bw,), generator=gen).to(DEV)
+        e_big = decw(xs, tt, ss, None)
+        e_small = decw(xs[:2].contiguous(), tt[:2].contiguous(), ss[:2].contiguous(), None)
+        assert torch.equal(e_small, e_big[:2]), (window, T)
