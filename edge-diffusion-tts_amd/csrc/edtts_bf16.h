@@ -32,10 +32,14 @@ typedef float f2v __attribute__((ext_vector_type(2)));
 namespace edtts16 {
 using namespace edtts;
 
-template <int H_, int HEADS_, int MEL_>
+// NF_ = 16-frame tiles per wave.  NF = 2: four waves per block (one per SIMD, up to 512 registers each).  NF = 1: EIGHT waves per
+// block, two per SIMD (<= 256 registers each): one wave's waits and softmax arithmetic run under the other's MFMAs -- with one
+// wave per SIMD 27 % of the cycles were s_waitcnt time and 24 % issue stalls -- at the price of LDS bandwidth (every wave reads
+// every weight fragment: 8 KiB per fragment and block).
+template <int H_, int HEADS_, int MEL_, int NF_ = 2>
 struct Cfg16 {
-  static constexpr int H = H_, HEADS = HEADS_, MEL = MEL_, NF = 2;
-  static constexpr int WF = 32;                 // frames per wave
+  static constexpr int H = H_, HEADS = HEADS_, MEL = MEL_, NF = NF_;
+  static constexpr int WF = 16 * NF;            // frames per wave
   static constexpr int DH = H / HEADS;          // head dim: one k-tile
   static constexpr int HT = H / 16;             // n-tiles of the hidden dim
   static constexpr int KT = H / 32;             // k-tiles of the hidden dim (= heads)
@@ -44,14 +48,19 @@ struct Cfg16 {
   static constexpr int MTP = (MT + 1) / 2;      // n-tile PAIRS of the mel dim (the last one may be half empty)
   static constexpr int R = H / 2;
   static constexpr int VR = H;                  // rows of a v^T buffer
-  static constexpr int WAVES = 4, THREADS = 64 * WAVES;
+#ifndef EDTTS16_W1
+#define EDTTS16_W1 4   // waves per block of the NF = 1 variant: 8 = one block per CU, two waves per SIMD in lockstep; 4 = two independent blocks per CU
+#endif
+  static constexpr int WAVES = NF == 2 ? 4 : EDTTS16_W1, THREADS = 64 * WAVES;
+  static constexpr int MIN_WAVES_PER_SIMD = NF == 2 ? 1 : 2;
   // Weight stream: every GEMM unit of the kernels (an n-tile pair over all k-tiles, or one k-tile over all n-tiles) consumes
   // exactly PH = HT fragments (1 KiB each) -- one PHASE.  The block shares one LDS ring of NS phase slots (see LdsRing).
   static constexpr int PH = HT;                 // fragments per phase
-  static constexpr int NS = 6;                  // ring slots (phases): NS - 1 phases are in flight ahead of the consumers
+  static constexpr int NS = (NF == 1 && WAVES == 4) ? 4 : 6;  // ring slots (phases): NS - 1 phases are in flight ahead of the consumers
   static constexpr int PARAM_FLOATS = 4 * H + MEL;  // FFN up bias (stream order) + out_proj bias, staged in LDS (see k_layer16)
   static constexpr int LDS_BYTES = NS * PH * 1024 + PARAM_FLOATS * 4;
   static_assert(DH == 32, "the bf16 instance is built for head_dim 32 (one MFMA k-tile per head)");
+  static_assert(NF == 1 || NF == 2, "frame tiles per wave");
   static_assert(H % 64 == 0 && MEL % 16 == 0 && PH % WAVES == 0 && LDS_BYTES <= 160 * 1024, "dims vs ring");
 };
 
@@ -62,6 +71,13 @@ EDTTS_DEV bf8 pack8(f4 a, f4 b) {
   const bf2 p0 = __builtin_convertvector(f2v{a[0], a[1]}, bf2), p1 = __builtin_convertvector(f2v{a[2], a[3]}, bf2);
   const bf2 p2 = __builtin_convertvector(f2v{b[0], b[1]}, bf2), p3 = __builtin_convertvector(f2v{b[2], b[3]}, bf2);
   return bf8{p0[0], p0[1], p1[0], p1[1], p2[0], p2[1], p3[0], p3[1]};
+}
+typedef float f2s __attribute__((ext_vector_type(2)));
+// four C/D registers -> 4 bf16 (8 bytes)
+EDTTS_DEV f2s pack4(f4 a) {
+  const bf2 p0 = __builtin_convertvector(f2v{a[0], a[1]}, bf2), p1 = __builtin_convertvector(f2v{a[2], a[3]}, bf2);
+  typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
+  return __builtin_bit_cast(f2s, bf4{p0[0], p0[1], p1[0], p1[1]});
 }
 EDTTS_DEV bf8 ldg_bf8(const __bf16* base, unsigned byte_off) {
   return *reinterpret_cast<const bf8*>(reinterpret_cast<const char*>(base) + byte_off);
@@ -122,7 +138,7 @@ template <class C> using Ring16 = LdsRing<C>;
 // two n-tiles at once from a phase that interleaves their fragments per k-tile ([kt][tile a | tile b]).
 // SWAP: activations as the A operand, weights as B -> C/D = [frame][feature] (used for v^T).
 template <int KT, bool SWAP, class C>
-EDTTS_DEV void gemm16_pair(LdsRing<C>& ring, const bf8 (&in)[KT][2], f4 (&a)[2], f4 (&b)[2]) {
+EDTTS_DEV void gemm16_pair(LdsRing<C>& ring, const bf8 (&in)[KT][C::NF], f4 (&a)[C::NF], f4 (&b)[C::NF]) {
   static_assert(2 * KT == C::PH, "an n-tile pair over all k-tiles is one phase");
   const f4* fr = ring.acquire();
   // all fragments of the phase are requested from LDS up front (in-order returns: the MFMAs wait with a counted lgkmcnt each),
@@ -137,7 +153,7 @@ EDTTS_DEV void gemm16_pair(LdsRing<C>& ring, const bf8 (&in)[KT][2], f4 (&a)[2],
   for (int kt = 0; kt < KT; ++kt) {
     const bf8 fa = as_bf8(fg[2 * kt]), fb = as_bf8(fg[2 * kt + 1]);
 #pragma unroll
-    for (int ft = 0; ft < 2; ++ft) {
+    for (int ft = 0; ft < C::NF; ++ft) {
       a[ft] = SWAP ? EDTTS_MFMA16(in[kt][ft], fa, a[ft]) : EDTTS_MFMA16(fa, in[kt][ft], a[ft]);
       b[ft] = SWAP ? EDTTS_MFMA16(in[kt][ft], fb, b[ft]) : EDTTS_MFMA16(fb, in[kt][ft], b[ft]);
     }
@@ -145,7 +161,7 @@ EDTTS_DEV void gemm16_pair(LdsRing<C>& ring, const bf8 (&in)[KT][2], f4 (&a)[2],
 }
 // acc[nt] += frag(nt) * in  for one k-tile of a k-major packed matrix (NT fragments = one phase)
 template <int NT, class C>
-EDTTS_DEV void ktile16(LdsRing<C>& ring, const bf8 (&in)[2], f4 (&acc)[NT][2]) {
+EDTTS_DEV void ktile16(LdsRing<C>& ring, const bf8 (&in)[C::NF], f4 (&acc)[NT][C::NF]) {
   static_assert(NT == C::PH, "one k-tile over all n-tiles is one phase");
   const f4* fr = ring.acquire();
   f4 fg[NT];
@@ -155,18 +171,19 @@ EDTTS_DEV void ktile16(LdsRing<C>& ring, const bf8 (&in)[2], f4 (&acc)[NT][2]) {
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     const bf8 fa = as_bf8(fg[nt]);
-    acc[nt][0] = EDTTS_MFMA16(fa, in[0], acc[nt][0]);
-    acc[nt][1] = EDTTS_MFMA16(fa, in[1], acc[nt][1]);
+#pragma unroll
+    for (int ft = 0; ft < C::NF; ++ft) acc[nt][ft] = EDTTS_MFMA16(fa, in[ft], acc[nt][ft]);
   }
 }
 
 // RMSNorm (+ optional AdaLN modulation) of the residual tile, straight into packed bf16 B operands
 template <class C>
-EDTTS_DEV void rms_norm_pack(const f4 (&x)[C::HT][2], const float* __restrict__ w, const float* __restrict__ mod, int g,
-                             bf8 (&y)[C::KT][2]) {
-  float rs[2];
+EDTTS_DEV void rms_norm_pack(const f4 (&x)[C::HT][C::NF], const float* __restrict__ w, const float* __restrict__ mod, int g,
+                             bf8 (&y)[C::KT][C::NF]) {
+  constexpr int NF = C::NF;
+  float rs[NF];
 #pragma unroll
-  for (int ft = 0; ft < 2; ++ft) {
+  for (int ft = 0; ft < NF; ++ft) {
     float ss = 0.f;
 #pragma unroll
     for (int t = 0; t < C::HT; ++t) ss += hsum(x[t][ft] * x[t][ft]);
@@ -174,7 +191,7 @@ EDTTS_DEV void rms_norm_pack(const f4 (&x)[C::HT][2], const float* __restrict__ 
   }
 #pragma unroll
   for (int kt = 0; kt < C::KT; ++kt) {
-    f4 v[2][2];
+    f4 v[2][NF];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int t = 2 * kt + u;
@@ -185,22 +202,23 @@ EDTTS_DEV void rms_norm_pack(const f4 (&x)[C::HT][2], const float* __restrict__ 
         sh = ldg4(mod + C::H + 16 * t + 4 * g);
       }
 #pragma unroll
-      for (int ft = 0; ft < 2; ++ft) {
+      for (int ft = 0; ft < NF; ++ft) {
         f4 a = x[t][ft] * rs[ft] * wv;
         if (mod != nullptr) a = a * sc + sh;
         v[u][ft] = a;
       }
     }
-    y[kt][0] = pack8(v[0][0], v[1][0]);
-    y[kt][1] = pack8(v[0][1], v[1][1]);
+#pragma unroll
+    for (int ft = 0; ft < NF; ++ft) y[kt][ft] = pack8(v[0][ft], v[1][ft]);
   }
 }
 template <class C>
-EDTTS_DEV void layer_norm_pack(const f4 (&x)[C::HT][2], const float* __restrict__ w, const float* __restrict__ b, int g,
-                               bf8 (&y)[C::KT][2]) {
-  float mu[2], rs[2];
+EDTTS_DEV void layer_norm_pack(const f4 (&x)[C::HT][C::NF], const float* __restrict__ w, const float* __restrict__ b, int g,
+                               bf8 (&y)[C::KT][C::NF]) {
+  constexpr int NF = C::NF;
+  float mu[NF], rs[NF];
 #pragma unroll
-  for (int ft = 0; ft < 2; ++ft) {
+  for (int ft = 0; ft < NF; ++ft) {
     float s = 0.f;
 #pragma unroll
     for (int t = 0; t < C::HT; ++t) s += hsum(x[t][ft]);
@@ -215,16 +233,16 @@ EDTTS_DEV void layer_norm_pack(const f4 (&x)[C::HT][2], const float* __restrict_
   }
 #pragma unroll
   for (int kt = 0; kt < C::KT; ++kt) {
-    f4 v[2][2];
+    f4 v[2][NF];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int t = 2 * kt + u;
       const f4 wv = ldg4(w + 16 * t + 4 * g), bv = ldg4(b + 16 * t + 4 * g);
 #pragma unroll
-      for (int ft = 0; ft < 2; ++ft) v[u][ft] = (x[t][ft] - mu[ft]) * rs[ft] * wv + bv;
+      for (int ft = 0; ft < NF; ++ft) v[u][ft] = (x[t][ft] - mu[ft]) * rs[ft] * wv + bv;
     }
-    y[kt][0] = pack8(v[0][0], v[1][0]);
-    y[kt][1] = pack8(v[0][1], v[1][1]);
+#pragma unroll
+    for (int ft = 0; ft < NF; ++ft) y[kt][ft] = pack8(v[0][ft], v[1][ft]);
   }
 }
 
@@ -239,18 +257,21 @@ EDTTS_DEV void layer_norm_pack(const f4 (&x)[C::HT][2], const float* __restrict_
 // ---------------------------------------------------------------------------------------------------------
 template <class C, bool SELF, class QF>
 EDTTS_DEV void attention16(QF&& qf, const __bf16* __restrict__ Kb, const __bf16* __restrict__ VTb, int kpad, int nkeys,
-                           int window, int m0, int lane, Ring16<C>& ring, f4 (&delta)[C::HT][2]) {
+                           int window, int m0, int lane, Ring16<C>& ring, f4 (&delta)[C::HT][C::NF]) {
+  constexpr int NF = C::NF;
   // Kb / VTb: this utterance's K / V^T images, TILE-CONTIGUOUS: K[head][key tile][16 keys][32 d-slots] and
   // V^T[head][32-key chunk][2 d-tiles][16 d][32 key-slots] -- every MFMA operand tile is one contiguous KiB, i.e. one fully
   // coalesced load per wave (kpad = padded key count: head stride = 32 * kpad elements in both images).
   const int fq = lane & 15, g = lane >> 4;
   const float NEG_INF = -__builtin_inff();
-  // chunk geometry (one half: NF = 2), as in edtts_device.h attention_fused
+  // chunk geometry as in edtts_device.h attention_fused: partition and order are those of the enclosing 32-frame pair of query
+  // tiles (mg), also when the wave owns one tile (NF = 1); the per-lane band limits use the wave's own rows
+  const int mg = m0 & ~31;
   int kt_lo, kt_hi;
   if (SELF && window >= 0) {
-    const int lo = m0 - window;
+    const int lo = mg - window;
     kt_lo = ((lo > 0 ? lo : 0) >> 4) & ~1;
-    const int hi = m0 + 31 + window;
+    const int hi = mg + 31 + window;
     const int last = hi < nkeys - 1 ? hi : nkeys - 1;
     kt_hi = (last >> 4) + 1;
   } else {
@@ -258,13 +279,13 @@ EDTTS_DEV void attention16(QF&& qf, const __bf16* __restrict__ Kb, const __bf16*
     kt_hi = (nkeys + 15) >> 4;
   }
   const int nchunk = (kt_hi - kt_lo + 1) / 2;
-  const bool off_grid = SELF && window >= 0 && (m0 - window > (kt_lo << 4));
-  int cdiag = off_grid ? ((m0 >> 4) - kt_lo) / 2 : 0;
+  const bool off_grid = SELF && window >= 0 && (mg - window > (kt_lo << 4));
+  int cdiag = off_grid ? ((mg >> 4) - kt_lo) / 2 : 0;
   if (cdiag >= nchunk) cdiag = nchunk - 1;
   const int klim = (kt_hi << 4) < nkeys ? (kt_hi << 4) : nkeys;
-  int lo_d[2], span[2];
+  int lo_d[NF], span[NF];
 #pragma unroll
-  for (int ft = 0; ft < 2; ++ft) {
+  for (int ft = 0; ft < NF; ++ft) {
     const int qi = m0 + 16 * ft + fq;
     int lo = -(1 << 28), hi = klim - 1 - qi;
     if (SELF && window >= 0) {
@@ -296,14 +317,14 @@ EDTTS_DEV void attention16(QF&& qf, const __bf16* __restrict__ Kb, const __bf16*
     c = clampc(c);
     const int k0 = (kt_lo + 2 * c) << 4, k1 = k0 + 31;
     bool full = k1 < klim && (kt_lo + 2 * (c + 1)) <= kt_hi;
-    if (SELF && window >= 0) full = full && (k1 - m0 <= window) && (k0 - (m0 + 31) >= -window);
+    if (SELF && window >= 0) full = full && (k1 - m0 <= window) && (k0 - (m0 + 16 * NF - 1) >= -window);
     return full;
   };
-  auto mask_init = [&](int c, f4 (&S)[2][2], const float (&vis)[2]) {
+  auto mask_init = [&](int c, f4 (&S)[2][NF], const float (&vis)[NF]) {
     c = clampc(c);
     const int k0 = (kt_lo + 2 * c) << 4;
 #pragma unroll
-    for (int ft = 0; ft < 2; ++ft) {
+    for (int ft = 0; ft < NF; ++ft) {
       const int d0 = k0 + 4 * g - (m0 + 16 * ft + fq) - lo_d[ft];
       const unsigned sp = span[ft] >= 0 ? (unsigned)span[ft] : 0u;
       const int bias = span[ft] >= 0 ? 0 : (1 << 30);
@@ -318,10 +339,10 @@ EDTTS_DEV void attention16(QF&& qf, const __bf16* __restrict__ Kb, const __bf16*
 
   // K / V^T operands are double-buffered: the tiles of step s + 2 are requested while step s computes (with one wave per SIMD
   // nothing else hides an L2 round trip: measured, with a one-step distance 40 % of the wave's cycles were s_waitcnt time)
-  bf8 KA0[2], VA0[2], KA1[2], VA1[2], q[2];
+  bf8 KA0[2], VA0[2], KA1[2], VA1[2], q[NF];
   auto prefetch = [&](int hd) {
-    q[0] = qf(hd, 0);
-    q[1] = qf(hd, 1);
+#pragma unroll
+    for (int ft = 0; ft < NF; ++ft) q[ft] = qf(hd, ft);
     load_k(hd, chunk_of(0), KA0);
     load_v(hd, chunk_of(0), VA0);
     load_k(hd, chunk_of(1), KA1);
@@ -329,26 +350,29 @@ EDTTS_DEV void attention16(QF&& qf, const __bf16* __restrict__ Kb, const __bf16*
   };
   prefetch(0);
   for (int hd = 0; hd < C::HEADS; ++hd) {
-    f4 O[2][2] = {{splat(0.f), splat(0.f)}, {splat(0.f), splat(0.f)}};
-    f4 lvec[2] = {splat(0.f), splat(0.f)};
-    f4 NM[2] = {splat(0.f), splat(0.f)};
-    float nm[2] = {0.f, 0.f};
+    f4 O[2][NF], lvec[NF], NM[NF];
+    float nm[NF];
+#pragma unroll
+    for (int ft = 0; ft < NF; ++ft) {
+      O[0][ft] = O[1][ft] = lvec[ft] = NM[ft] = splat(0.f);
+      nm[ft] = 0.f;
+    }
     auto step = [&](bool first, int c, int cnext2, bf8 (&KA)[2], bf8 (&VA)[2]) {
-      f4 S[2][2];
+      f4 S[2][NF];
       if (chunk_is_interior(c)) {
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-          for (int ft = 0; ft < 2; ++ft) S[t][ft] = NM[ft];  // first step: NM = 0
+          for (int ft = 0; ft < NF; ++ft) S[t][ft] = NM[ft];  // first step: NM = 0
       } else {
         mask_init(c, S, nm);  // first step: nm = 0
       }
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int ft = 0; ft < 2; ++ft) S[t][ft] = EDTTS_MFMA16(KA[t], q[ft], S[t][ft]);
+        for (int ft = 0; ft < NF; ++ft) S[t][ft] = EDTTS_MFMA16(KA[t], q[ft], S[t][ft]);
       load_k(hd, cnext2, KA);  // (re-reads a valid tile past the last step)
-      f4 P[2][2], ps[2];
+      f4 P[2][NF], ps[NF];
       auto lane_max = [&](int ft) {
         f4 mv = S[0][ft];
 #pragma unroll
@@ -364,7 +388,7 @@ EDTTS_DEV void attention16(QF&& qf, const __bf16* __restrict__ Kb, const __bf16*
       };
       if (first) {
 #pragma unroll
-        for (int ft = 0; ft < 2; ++ft) {
+        for (int ft = 0; ft < NF; ++ft) {
           const float gm = group_max(lane_max(ft));
           const float m = gm > -1e30f ? gm : 0.f;
           nm[ft] = -m;
@@ -372,12 +396,16 @@ EDTTS_DEV void attention16(QF&& qf, const __bf16* __restrict__ Kb, const __bf16*
           exp_and_sum(ft, m);
         }
       } else {
-        exp_and_sum(0, 0.f);
-        exp_and_sum(1, 0.f);
         const float lim = 4294967296.f;  // 2^32 (kDefer)
-        if (__any(!(hsum(ps[0]) <= lim) || !(hsum(ps[1]) <= lim))) {
+        bool over = false;
 #pragma unroll
-          for (int ft = 0; ft < 2; ++ft) {
+        for (int ft = 0; ft < NF; ++ft) {
+          exp_and_sum(ft, 0.f);
+          over = over || !(hsum(ps[ft]) <= lim);
+        }
+        if (__any(over)) {
+#pragma unroll
+          for (int ft = 0; ft < NF; ++ft) {
             const float dl = fmaxf(0.f, group_max(lane_max(ft)));
             const float alpha = fast_exp2(-dl);
             nm[ft] -= dl;
@@ -389,14 +417,16 @@ EDTTS_DEV void attention16(QF&& qf, const __bf16* __restrict__ Kb, const __bf16*
           }
         }
       }
-      lvec[0] += ps[0];
-      lvec[1] += ps[1];
-      const bf8 pb0 = pack8(P[0][0], P[1][0]), pb1 = pack8(P[0][1], P[1][1]);
+      bf8 pb[NF];
 #pragma unroll
-      for (int dt = 0; dt < 2; ++dt) {
-        O[dt][0] = EDTTS_MFMA16(VA[dt], pb0, O[dt][0]);
-        O[dt][1] = EDTTS_MFMA16(VA[dt], pb1, O[dt][1]);
+      for (int ft = 0; ft < NF; ++ft) {
+        lvec[ft] += ps[ft];
+        pb[ft] = pack8(P[0][ft], P[1][ft]);
       }
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int ft = 0; ft < NF; ++ft) O[dt][ft] = EDTTS_MFMA16(VA[dt], pb[ft], O[dt][ft]);
       load_v(hd, cnext2, VA);
     };
     step(true, chunk_of(0), chunk_of(2), KA0, VA0);
@@ -404,9 +434,9 @@ EDTTS_DEV void attention16(QF&& qf, const __bf16* __restrict__ Kb, const __bf16*
       step(false, chunk_of(st), chunk_of(st + 2), KA1, VA1);
       if (st + 1 < nchunk) step(false, chunk_of(st + 1), chunk_of(st + 3), KA0, VA0);
     }
-    bf8 ob[2];
+    bf8 ob[NF];
 #pragma unroll
-    for (int ft = 0; ft < 2; ++ft) {
+    for (int ft = 0; ft < NF; ++ft) {
       const float lt = group_sum(hsum(lvec[ft]));
       const float inv = lt > 0.f ? 1.0f / lt : 0.f;
       ob[ft] = pack8(O[0][ft] * inv, O[1][ft] * inv);
@@ -421,7 +451,8 @@ EDTTS_DEV void attention16(QF&& qf, const __bf16* __restrict__ Kb, const __bf16*
 // [B][H][Tp] (slot order inside each 32-key chunk) -- layers/attention.py:91-93
 // ---------------------------------------------------------------------------------------------------------
 template <class C>
-EDTTS_DEV void qkv_tail16(Ring16<C>& ring, const bf8 (&hn)[C::KT][2], const KArgs& a, int b, int m0, int lane, bool valid) {
+EDTTS_DEV void qkv_tail16(Ring16<C>& ring, const bf8 (&hn)[C::KT][C::NF], const KArgs& a, int b, int m0, int lane, bool valid) {
+  constexpr int NF = C::NF;
   const int fq = lane & 15, g = lane >> 4;
   const size_t rowbase = (size_t)b * a.Tp + m0 + fq;
   __bf16* const qo = reinterpret_cast<__bf16*>(a.q_out);
@@ -430,7 +461,9 @@ EDTTS_DEV void qkv_tail16(Ring16<C>& ring, const bf8 (&hn)[C::KT][2], const KArg
 #pragma unroll
   for (int which = 0; which < 2; ++which) {
     for (int p = 0; p < C::KT; ++p) {
-      f4 acc[2][2] = {{splat(0.f), splat(0.f)}, {splat(0.f), splat(0.f)}};
+      f4 acc[2][NF];
+#pragma unroll
+      for (int ft = 0; ft < NF; ++ft) acc[0][ft] = acc[1][ft] = splat(0.f);
       gemm16_pair<C::KT, false>(ring, hn, acc[0], acc[1]);
       // q: row-major [frame][H] (read back by this wave only); k: tile-contiguous image [head p][key tile][16 keys][32 slots].
       // PLAIN stores, not streaming ones: on gfx9 stores retire through the same in-order vmcnt as the ring's DMAs, and a
@@ -440,18 +473,24 @@ EDTTS_DEV void qkv_tail16(Ring16<C>& ring, const bf8 (&hn)[C::KT][2], const KArg
       const size_t fstride = which == 0 ? (size_t)16 * C::H : 512;
       if (valid)
 #pragma unroll
-      for (int ft = 0; ft < 2; ++ft)
+      for (int ft = 0; ft < NF; ++ft)
         *reinterpret_cast<f4*>(dst + ft * fstride) = as_f4(pack8(acc[0][ft], acc[1][ft]));
     }
   }
   for (int p = 0; p < C::KT; ++p) {
-    f4 acc[2][2] = {{splat(0.f), splat(0.f)}, {splat(0.f), splat(0.f)}};
+    f4 acc[2][NF];
+#pragma unroll
+    for (int ft = 0; ft < NF; ++ft) acc[0][ft] = acc[1][ft] = splat(0.f);
     gemm16_pair<C::KT, true>(ring, hn, acc[0], acc[1]);  // C/D = [frame 4g+r of tile ft][feature 16(2p+u) + fq]
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      // v^T image: [head p][32-key chunk][d-tile u][16 d][32 key slots]
+      // v^T image: [head p][32-key chunk][d-tile u][16 d][32 key slots]; key 16 t + 4 g + r of the chunk sits at slot 8 g + 4 t + r
       __bf16* dst = vo + ((size_t)(b * C::HEADS + p) * (a.Tp >> 5) + (m0 >> 5)) * 1024 + u * 512 + fq * 32 + 8 * g;
-      if (valid) *reinterpret_cast<f4*>(dst) = as_f4(pack8(acc[u][0], acc[u][1]));
+      if (NF == 2) {
+        if (valid) *reinterpret_cast<f4*>(dst) = as_f4(pack8(acc[u][0], acc[u][NF - 1]));
+      } else {  // one 16-frame tile per wave: its 4 keys per lane are half of the 8-slot group (t = tile parity inside the chunk)
+        if (valid) *reinterpret_cast<f2s*>(dst + 4 * ((m0 >> 4) & 1)) = pack4(acc[u][0]);
+      }
     }
   }
 }
@@ -460,7 +499,7 @@ EDTTS_DEV void qkv_tail16(Ring16<C>& ring, const bf8 (&hn)[C::KT][2], const KArg
 // prologue: h = in_proj(x) + pe ; AdaRMSNorm(layer 0) ; QKV(layer 0)
 // =========================================================================================================
 template <class C>
-__global__ __launch_bounds__(C::THREADS) void k_prologue16(KArgs a) {
+__global__ __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) void k_prologue16(KArgs a) {
   extern __shared__ __attribute__((aligned(16))) f4 ring_lds16[];
   // (a padding wave of the last block works on a copy of the last tile -- it takes part in the ring's barriers and DMAs -- and
   // stores nothing)
@@ -470,9 +509,10 @@ __global__ __launch_bounds__(C::THREADS) void k_prologue16(KArgs a) {
   const int b = tl.b, m0 = tl.m0;
   Ring16<C> ring;
   ring.start(a.stream, ring_lds16, __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane);
-  bf8 xin[C::MKT][2];
+  constexpr int NF = C::NF;
+  bf8 xin[C::MKT][NF];
 #pragma unroll
-  for (int ft = 0; ft < 2; ++ft) {
+  for (int ft = 0; ft < NF; ++ft) {
     const int f = m0 + 16 * ft + fq;
     const float* xr = a.x + ((size_t)b * a.T + f) * C::MEL;
 #pragma unroll
@@ -483,13 +523,15 @@ __global__ __launch_bounds__(C::THREADS) void k_prologue16(KArgs a) {
       xin[kt][ft] = pack8(v0, v1);
     }
   }
-  f4 h[C::HT][2];
+  f4 h[C::HT][NF];
 #pragma unroll
-  for (int nt = 0; nt < C::HT; ++nt) h[nt][0] = h[nt][1] = ldg4(a.inp_b + 16 * nt + 4 * g);
+  for (int nt = 0; nt < C::HT; ++nt)
+#pragma unroll
+    for (int ft = 0; ft < NF; ++ft) h[nt][ft] = ldg4(a.inp_b + 16 * nt + 4 * g);
 #pragma unroll
   for (int kt = 0; kt < C::MKT; ++kt) ktile16<C::HT>(ring, xin[kt], h);
 #pragma unroll
-  for (int ft = 0; ft < 2; ++ft) {
+  for (int ft = 0; ft < NF; ++ft) {
     int f = m0 + 16 * ft + fq;
     f = f < a.max_pos ? f : a.max_pos - 1;
 #pragma unroll
@@ -500,9 +542,9 @@ __global__ __launch_bounds__(C::THREADS) void k_prologue16(KArgs a) {
 #pragma unroll
     for (int nt = 0; nt < C::HT; ++nt)
 #pragma unroll
-      for (int ft = 0; ft < 2; ++ft) stg4(hp + 16 * nt + (size_t)ft * 16 * C::H, h[nt][ft]);
+      for (int ft = 0; ft < NF; ++ft) stg4(hp + 16 * nt + (size_t)ft * 16 * C::H, h[nt][ft]);
   }
-  bf8 hn[C::KT][2];
+  bf8 hn[C::KT][NF];
   rms_norm_pack<C>(h, a.n1w, a.cond + (size_t)b * a.cond_bstride, g, hn);
   qkv_tail16<C>(ring, hn, a, b, m0, lane, valid);
   ring.drain();
@@ -512,7 +554,7 @@ __global__ __launch_bounds__(C::THREADS) void k_prologue16(KArgs a) {
 // transformer layer kernel (bf16 contractions)
 // =========================================================================================================
 template <class C, int TAIL>
-__global__ __launch_bounds__(C::THREADS) void k_layer16(KArgs a) {
+__global__ __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) void k_layer16(KArgs a) {
   extern __shared__ __attribute__((aligned(16))) f4 ring_lds16[];
   const TileId tl = wave_tile(a.B, a.Tp, C::WAVES, C::WF);
   const bool valid = tl.valid;  // a padding wave works on a copy of the last tile (ring barriers, DMAs) and stores nothing
@@ -533,13 +575,14 @@ __global__ __launch_bounds__(C::THREADS) void k_layer16(KArgs a) {
   // residual tile (fp32).  Unlike the fp32 kernel, the branches accumulate straight into it: the rounding of the partial sums at
   // the residual's magnitude (~1e-6) is three orders below the bf16 operand rounding, and a separate branch tile would cost 128
   // more registers (measured: spills, whose scratch reloads force s_waitcnt vmcnt(0) and drain the weight ring).
-  f4 h[C::HT][2];
+  constexpr int NF = C::NF;
+  f4 h[C::HT][NF];
   float* const hp = a.h + rowbase * C::H + 4 * g;
 #pragma unroll
   for (int nt = 0; nt < C::HT; ++nt) {
     const f4 pb = ldg4(a.proj_b + 16 * nt + 4 * g);
 #pragma unroll
-    for (int ft = 0; ft < 2; ++ft) h[nt][ft] = ldg4(hp + 16 * nt + (size_t)ft * 16 * C::H) + pb;
+    for (int ft = 0; ft < NF; ++ft) h[nt][ft] = ldg4(hp + 16 * nt + (size_t)ft * 16 * C::H) + pb;
   }
   // ---- x = x + attn(norm1(x, cond))   (transformer.py:142-146; q / k / v^T were produced by the previous kernel) ----
   {
@@ -550,19 +593,21 @@ __global__ __launch_bounds__(C::THREADS) void k_layer16(KArgs a) {
   }
   // ---- x = x + cross_attn(norm2(x), context)   (transformer.py:151, mla.py:118-194) ----
   {
-    bf8 qx[C::KT][2];
+    bf8 qx[C::KT][NF];
     {
-      bf8 hn[C::KT][2];
+      bf8 hn[C::KT][NF];
       rms_norm_pack<C>(h, a.n2w, nullptr, g, hn);
       for (int p = 0; p < C::KT; ++p) {
-        f4 acc[2][2] = {{splat(0.f), splat(0.f)}, {splat(0.f), splat(0.f)}};
+        f4 acc[2][NF];
+#pragma unroll
+        for (int ft = 0; ft < NF; ++ft) acc[0][ft] = acc[1][ft] = splat(0.f);
         gemm16_pair<C::KT, false>(ring, hn, acc[0], acc[1]);
         // (a runtime-indexed register array would go to scratch: write through a fully unrolled select)
 #pragma unroll
         for (int pp = 0; pp < C::KT; ++pp)
           if (pp == p) {
-            qx[pp][0] = pack8(acc[0][0], acc[1][0]);
-            qx[pp][1] = pack8(acc[0][1], acc[1][1]);
+#pragma unroll
+            for (int ft = 0; ft < NF; ++ft) qx[pp][ft] = pack8(acc[0][ft], acc[1][ft]);
           }
       }
     }
@@ -578,24 +623,26 @@ __global__ __launch_bounds__(C::THREADS) void k_layer16(KArgs a) {
   }
   // ---- x = x + ffn(norm3(x, cond))   (transformer.py:154-158, :13-49) ----
   {
-    bf8 hn[C::KT][2];
+    bf8 hn[C::KT][NF];
     rms_norm_pack<C>(h, a.n3w, a.cond + (size_t)b * a.cond_bstride + ((size_t)a.layer * 2 + 1) * 2 * C::H, g, hn);
 #pragma unroll
     for (int nt = 0; nt < C::HT; ++nt) {
       const f4 db = ldg4(a.down_b + 16 * nt + 4 * g);
-      h[nt][0] += db;
-      h[nt][1] += db;
+#pragma unroll
+      for (int ft = 0; ft < NF; ++ft) h[nt][ft] += db;
     }
     for (int jp = 0; jp < C::HT; ++jp) {  // 2H hidden features = HT k-tiles of the down projection
-      f4 act[2][2];
+      f4 act[2][NF];
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const int j = 2 * jp + u;
-        f4 v[2] = {splat(0.f), splat(0.f)}, gt[2] = {splat(0.f), splat(0.f)};
+        f4 v[NF], gt[NF];
+#pragma unroll
+        for (int ft = 0; ft < NF; ++ft) v[ft] = gt[ft] = splat(0.f);
         gemm16_pair<C::KT, false>(ring, hn, v, gt);
         const f4 vb = *reinterpret_cast<const f4*>(params + 32 * j + 4 * g), gb = *reinterpret_cast<const f4*>(params + 32 * j + 16 + 4 * g);
 #pragma unroll
-        for (int ft = 0; ft < 2; ++ft) {
+        for (int ft = 0; ft < NF; ++ft) {
           v[ft] += vb;
           gt[ft] += gb;
           const f4 e = {fast_exp2(gt[ft][0] * -1.4426950408889634f), fast_exp2(gt[ft][1] * -1.4426950408889634f),
@@ -605,7 +652,9 @@ __global__ __launch_bounds__(C::THREADS) void k_layer16(KArgs a) {
           act[u][ft] = (v[ft] * gt[ft]) * rc;  // SwiGLU: value * silu(gate), transformer.py:21-23
         }
       }
-      const bf8 ab[2] = {pack8(act[0][0], act[1][0]), pack8(act[0][1], act[1][1])};
+      bf8 ab[NF];
+#pragma unroll
+      for (int ft = 0; ft < NF; ++ft) ab[ft] = pack8(act[0][ft], act[1][ft]);
       ktile16<C::HT>(ring, ab, h);
     }
   }
@@ -615,16 +664,18 @@ __global__ __launch_bounds__(C::THREADS) void k_layer16(KArgs a) {
 #pragma unroll
       for (int nt = 0; nt < C::HT; ++nt)
 #pragma unroll
-        for (int ft = 0; ft < 2; ++ft) stg4(hp + 16 * nt + (size_t)ft * 16 * C::H, h[nt][ft]);
+        for (int ft = 0; ft < NF; ++ft) stg4(hp + 16 * nt + (size_t)ft * 16 * C::H, h[nt][ft]);
     }
-    bf8 hn[C::KT][2];
+    bf8 hn[C::KT][NF];
     rms_norm_pack<C>(h, a.n1w, a.cond + (size_t)b * a.cond_bstride + ((size_t)(a.layer + 1) * 2) * 2 * C::H, g, hn);
     qkv_tail16<C>(ring, hn, a, b, m0, lane, valid);
   } else {
-    bf8 hn[C::KT][2];
+    bf8 hn[C::KT][NF];
     layer_norm_pack<C>(h, a.fnw, a.fnb, g, hn);
     for (int p = 0; p < C::MTP; ++p) {
-      f4 e[2][2] = {{splat(0.f), splat(0.f)}, {splat(0.f), splat(0.f)}};
+      f4 e[2][NF];
+#pragma unroll
+      for (int ft = 0; ft < NF; ++ft) e[0][ft] = e[1][ft] = splat(0.f);
       gemm16_pair<C::KT, false>(ring, hn, e[0], e[1]);
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
@@ -632,7 +683,7 @@ __global__ __launch_bounds__(C::THREADS) void k_layer16(KArgs a) {
         if (nt >= C::MT) continue;  // the padding half of the last pair
         const f4 ob = *reinterpret_cast<const f4*>(params + 4 * C::H + 16 * nt + 4 * g);
 #pragma unroll
-        for (int ft = 0; ft < 2; ++ft) {
+        for (int ft = 0; ft < NF; ++ft) {
           const int f = m0 + 16 * ft + fq;
           if (f >= a.T || !valid) continue;
           tail_apply<TAIL>(a, ((size_t)b * a.T + f) * C::MEL + 16 * nt + 4 * g, e[u][ft] + ob);

@@ -1412,6 +1412,10 @@ struct Launcher {
 };
 
 // ---- bf16 instance (edtts_bf16.h) ----------------------------------------------------------------------------
+// frame tiles per wave of the hidden-256 bf16 instance: 2 = four waves per block, 1 = eight (two per SIMD)
+#ifndef EDTTS16_NF
+#define EDTTS16_NF 2
+#endif
 template <class C>
 struct Launcher16 {
   using DdpmStep = DdpmStepArgs;
@@ -1521,7 +1525,7 @@ struct Launcher16 {
 #define EDTTS_DISPATCH(lo, ...)                                                                          \
   do {                                                                                                   \
     if ((lo).BF16) {                                                                                     \
-      if ((lo).H == 256 && (lo).HEADS == 8 && (lo).MEL == 80) { using LN = Launcher16<edtts16::Cfg16<256, 8, 80>>; __VA_ARGS__; } \
+      if ((lo).H == 256 && (lo).HEADS == 8 && (lo).MEL == 80) { using LN = Launcher16<edtts16::Cfg16<256, 8, 80, EDTTS16_NF>>; __VA_ARGS__; } \
       else if ((lo).H == 64 && (lo).HEADS == 2 && (lo).MEL == 80) { using LN = Launcher16<edtts16::Cfg16<64, 2, 80>>; __VA_ARGS__; } \
       else return fail(EDTTS_ERR_UNSUPPORTED, "no bf16 kernel instance for hidden=%d heads=%d n_mels=%d "  \
                        "(compiled: 256/8/80, 64/2/80)", (lo).H, (lo).HEADS, (lo).MEL);                     \
