@@ -360,17 +360,19 @@ EDTTS_DEV void attention16(QF&& qf, const __bf16* __restrict__ Kb, const __bf16*
     auto step = [&](bool first, int c, int cnext2, bf8 (&KA)[2], bf8 (&VA)[2]) {
       f4 S[2][NF];
       if (chunk_is_interior(c)) {
+        // the reference tile rides in as the C operand itself (written as S = NM; S = mfma(.., S) it cost 16 accumulator moves
+        // and as many reads per step); first step: NM = 0
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-          for (int ft = 0; ft < NF; ++ft) S[t][ft] = NM[ft];  // first step: NM = 0
+          for (int ft = 0; ft < NF; ++ft) S[t][ft] = EDTTS_MFMA16(KA[t], q[ft], NM[ft]);
       } else {
         mask_init(c, S, nm);  // first step: nm = 0
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int ft = 0; ft < NF; ++ft) S[t][ft] = EDTTS_MFMA16(KA[t], q[ft], S[t][ft]);
       }
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int ft = 0; ft < NF; ++ft) S[t][ft] = EDTTS_MFMA16(KA[t], q[ft], S[t][ft]);
       load_k(hd, cnext2, KA);  // (re-reads a valid tile past the last step)
       f4 P[2][NF], ps[NF];
       auto lane_max = [&](int ft) {
@@ -404,16 +406,33 @@ EDTTS_DEV void attention16(QF&& qf, const __bf16* __restrict__ Kb, const __bf16*
           over = over || !(hsum(ps[ft]) <= lim);
         }
         if (__any(over)) {
+          // Rare path.  Its inputs pass through a volatile asm: hipcc otherwise executes the whole path speculatively in EVERY step
+          // (if-conversion: the ISA showed 32 v_exp, 24 v_max and 16 v_sub per step instead of 16 / 0 / 0).
+          f4 T[2][NF];
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int ft = 0; ft < NF; ++ft) {
+              T[t][ft] = S[t][ft];
+              asm volatile("" : "+v"(T[t][ft]));
+            }
 #pragma unroll
           for (int ft = 0; ft < NF; ++ft) {
-            const float dl = fmaxf(0.f, group_max(lane_max(ft)));
+            f4 mv = T[0][ft];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mv[r] = fmaxf(mv[r], T[1][ft][r]);
+            const float dl = fmaxf(0.f, group_max(hmax(mv)));
             const float alpha = fast_exp2(-dl);
             nm[ft] -= dl;
             NM[ft] = splat(nm[ft]);
             lvec[ft] *= alpha;
             O[0][ft] *= alpha;
             O[1][ft] *= alpha;
-            exp_and_sum(ft, dl);
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) P[t][ft][r] = fast_exp2(T[t][ft][r] - dl);
+            ps[ft] = P[0][ft] + P[1][ft];
           }
         }
       }
