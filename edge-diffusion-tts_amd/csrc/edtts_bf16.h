@@ -572,6 +572,11 @@ __global__ __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) void k_prologue1
 // =========================================================================================================
 // transformer layer kernel (bf16 contractions)
 // =========================================================================================================
+#ifdef EDTTS_STAMPS
+#define STAMP16(i) do { if (a.stamps && blockIdx.x == 0 && threadIdx.x == 0) a.stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define STAMP16(i) do { } while (0)
+#endif
 template <class C, int TAIL>
 __global__ __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) void k_layer16(KArgs a) {
   extern __shared__ __attribute__((aligned(16))) f4 ring_lds16[];
@@ -603,6 +608,7 @@ __global__ __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) void k_layer16(K
 #pragma unroll
     for (int ft = 0; ft < NF; ++ft) h[nt][ft] = ldg4(hp + 16 * nt + (size_t)ft * 16 * C::H) + pb;
   }
+  STAMP16(0);
   // ---- x = x + attn(norm1(x, cond))   (transformer.py:142-146; q / k / v^T were produced by the previous kernel) ----
   {
     const __bf16* qrow = reinterpret_cast<const __bf16*>(a.q) + rowbase * C::H + 8 * g;
@@ -610,6 +616,7 @@ __global__ __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) void k_layer16(K
     attention16<C, true>(qf, reinterpret_cast<const __bf16*>(a.k) + (size_t)b * a.Tp * C::H,
                          reinterpret_cast<const __bf16*>(a.vT) + (size_t)b * C::H * a.Tp, a.Tp, a.T, a.window, m0, lane, ring, h);
   }
+  STAMP16(1);
   // ---- x = x + cross_attn(norm2(x), context)   (transformer.py:151, mla.py:118-194) ----
   {
     bf8 qx[C::KT][NF];
@@ -630,6 +637,7 @@ __global__ __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) void k_layer16(K
           }
       }
     }
+    STAMP16(2);
     auto qf = [&](int hd, int ft) {
       bf8 r = qx[0][ft];
 #pragma unroll
@@ -640,6 +648,7 @@ __global__ __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) void k_layer16(K
     attention16<C, false>(qf, reinterpret_cast<const __bf16*>(a.kc) + (size_t)b * a.Sp * C::H,
                           reinterpret_cast<const __bf16*>(a.vcT) + (size_t)b * C::H * a.Sp, a.Sp, a.S, -1, m0, lane, ring, h);
   }
+  STAMP16(3);
   // ---- x = x + ffn(norm3(x, cond))   (transformer.py:154-158, :13-49) ----
   {
     bf8 hn[C::KT][NF];
@@ -677,6 +686,7 @@ __global__ __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) void k_layer16(K
       ktile16<C::HT>(ring, ab, h);
     }
   }
+  STAMP16(4);
   // ---- tail ----
   if (TAIL == TAIL_QKV) {
     if (valid) {
@@ -710,7 +720,9 @@ __global__ __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) void k_layer16(K
       }
     }
   }
+  STAMP16(5);
   ring.drain();
+  STAMP16(6);
 }
 
 }  // namespace edtts16

@@ -392,6 +392,7 @@ struct KArgs {
   int cond_bstride;   // floats between batch rows (0 = one row shared by the batch)
   int layer;
   int diag_skip;  // EDTTS_DIAG builds only: bit0 self-attn, bit1 q_proj+cross-attn, bit2 ffn, bit3 tail
+  unsigned long long* stamps;  // EDTTS_STAMPS builds only: s_memtime stamps of block 0 / wave 0 (see edtts_debug_set_stamps)
   // weights
   const float *tok, *semp, *semp_b, *cpe, *inp, *inp_b, *pe;
   const float *n1w, *proj_b, *n2w, *n3w, *up_b, *down_b, *fnw, *fnb, *outp_b;
@@ -1411,6 +1412,9 @@ struct Launcher {
   }
 };
 
+#ifdef EDTTS_STAMPS
+static unsigned long long* g_stamps_fwd = nullptr;  // diagnostic builds only, see edtts_debug_set_stamps
+#endif
 // ---- bf16 instance (edtts_bf16.h) ----------------------------------------------------------------------------
 // frame tiles per wave of the hidden-256 bf16 instance: 2 = four waves per block, 1 = eight (two per SIMD)
 #ifndef EDTTS16_NF
@@ -1505,6 +1509,9 @@ struct Launcher16 {
         a.x_prev = x_prev; a.x0 = x0;
         a.c_s1m = coef[0]; a.c_sab = coef[1]; a.c_sabp = coef[2]; a.c_dir = coef[3];
       }
+#ifdef EDTTS_STAMPS
+      a.stamps = g_stamps_fwd ? g_stamps_fwd + 32 * l : nullptr;
+#endif
 #define EDTTS_LAUNCH16(TL) PROF_LAUNCH(st, hipLaunchKernelGGL((edtts16::k_layer16<C, TL>), dim3(g), dim3(C::THREADS), C::LDS_BYTES, st, a))
       switch (t_eff) {
         case TAIL_QKV: EDTTS_LAUNCH16(TAIL_QKV); break;
@@ -2045,6 +2052,14 @@ int edtts_griffin_lim(const float* spec, int B, int T, int n_fft, int hop, const
                            (size_t)hop * (T - 1) * sizeof(float), B, hipMemcpyDeviceToDevice, st));
   return EDTTS_OK;
 }
+
+#ifdef EDTTS_STAMPS
+// Diagnostic builds only (-DEDTTS_STAMPS; scratch/stamps_bf16.py): where block 0 / wave 0 of the bf16 layer kernel spends its cycles.
+int edtts_debug_set_stamps(void* device_buffer) {
+  g_stamps_fwd = (unsigned long long*)device_buffer;
+  return EDTTS_OK;
+}
+#endif
 
 int edtts_profile_enable(int max_records) {
   for (hipEvent_t e : g_prof.start) (void)hipEventDestroy(e);

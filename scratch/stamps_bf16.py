@@ -1,0 +1,27 @@
+"""Diagnostic (-DEDTTS_STAMPS build): cycle stamps of block 0 / wave 0 of the bf16 layer kernel, per layer.
+EDTTS_LIB=<stamps build> python scratch/stamps_bf16.py"""
+import ctypes as C, os, sys
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [os.path.join(REPO, "edge-diffusion-tts_amd"), REPO]
+import torch
+from edge_diffusion_tts_amd import CFG, EdgeDiffusionDecoder, synth_state_dict, native
+os.chdir("/tmp")
+cfg = CFG(hidden=256, layers=8, heads=8, device="cuda")
+dec = EdgeDiffusionDecoder(cfg, max_len=1024, compute_dtype="bf16"); dec.load_state_dict(synth_state_dict(cfg, 1, max_pos=1024)); dec = dec.cuda().eval()
+gen = torch.Generator().manual_seed(0)
+B, T, S = 256, 1024, 512
+x = torch.randn(B, T, 80, generator=gen).cuda(); sem = torch.randint(0, 512, (B, S), generator=gen).cuda()
+t = torch.full((B,), 500).cuda(); si = torch.zeros(B, dtype=torch.long).cuda()
+buf = torch.zeros(32 * 8, dtype=torch.int64, device="cuda")
+L = native.lib()
+L.edtts_debug_set_stamps.argtypes = [C.c_void_p]
+for _ in range(2): dec(x, t, sem, si)
+L.edtts_debug_set_stamps(buf.data_ptr())
+dec(x, t, sem, si); torch.cuda.synchronize()
+st = buf.cpu().view(8, 32)[:, :7]
+names = ["self-attn (8 heads: steps + proj phase)", "norm2 + q_proj (8 phases)", "cross-attn (8 heads x 16 steps + out_proj phase)", "norm3 + FFN (48 phases)", "tail: store h, norm, QKV (24 phases)", "drain"]
+for l in (1, 4):
+    d = (st[l, 1:] - st[l, :-1]).tolist()
+    tot = int(st[l, 6] - st[l, 0])
+    print(f"layer {l}: total {tot} memtime ticks (100 MHz constant clock? see below)")
+    for n, v in zip(names, d): print(f"   {n:55s} {v:9d}  {100.0*v/tot:5.1f} %")
