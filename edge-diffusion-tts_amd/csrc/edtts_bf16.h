@@ -29,6 +29,14 @@ typedef float f2v __attribute__((ext_vector_type(2)));
 
 #define EDTTS_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
 
+#ifdef EDTTS_STAMPS
+#define STAMP16(i) do { if (a.stamps && blockIdx.x == 0 && threadIdx.x == 0) a.stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#define STAMPX(p, i) do { if ((p) && blockIdx.x == 0 && threadIdx.x == 0) (p)[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define STAMP16(i) do { } while (0)
+#define STAMPX(p, i) do { } while (0)
+#endif
+
 namespace edtts16 {
 using namespace edtts;
 
@@ -257,8 +265,10 @@ EDTTS_DEV void layer_norm_pack(const f4 (&x)[C::HT][C::NF], const float* __restr
 // ---------------------------------------------------------------------------------------------------------
 template <class C, bool SELF, class QF>
 EDTTS_DEV void attention16(QF&& qf, const __bf16* __restrict__ Kb, const __bf16* __restrict__ VTb, int kpad, int nkeys,
-                           int window, int m0, int lane, Ring16<C>& ring, f4 (&delta)[C::HT][C::NF]) {
+                           int window, int m0, int lane, Ring16<C>& ring, f4 (&delta)[C::HT][C::NF], unsigned long long* stamps = nullptr) {
   constexpr int NF = C::NF;
+  int sidx = 0;  // (EDTTS_STAMPS diagnostic builds: fine-grained stamps of head 0)
+  (void)sidx; (void)stamps;
   // Kb / VTb: this utterance's K / V^T images, TILE-CONTIGUOUS: K[head][key tile][16 keys][32 d-slots] and
   // V^T[head][32-key chunk][2 d-tiles][16 d][32 key-slots] -- every MFMA operand tile is one contiguous KiB, i.e. one fully
   // coalesced load per wave (kpad = padded key count: head stride = 32 * kpad elements in both images).
@@ -298,26 +308,29 @@ EDTTS_DEV void attention16(QF&& qf, const __bf16* __restrict__ Kb, const __bf16*
   const unsigned toff = (unsigned)(fq * 32 + 8 * g) * 2u;  // this lane's 16 bytes inside a [16][32] tile
   const size_t hstride = (size_t)32 * kpad;               // elements between heads
   auto clampc = [&](int c) { return c < nchunk ? c : nchunk - 1; };
+  // A chunk = two key tiles = 2 KiB of the K image and 2 KiB (both d-tiles) of the V^T image, both contiguous: chunk c of head hd
+  // starts at kh / vh + 1024 c elements.  (A tile past kt_hi is read as it is -- the padded images hold finite values -- and masked.)
+  // Every instruction counts here: with one wave per SIMD an attention step is bound by its TOTAL instruction count (~5 cycles
+  // each, scalar ones included), so the per-step address and geometry arithmetic is kept to a clamp, a shift and an add.
+  const __bf16* const kh0 = Kb + (size_t)kt_lo * 512;
+  const __bf16* const vh0 = VTb + (size_t)(kt_lo >> 1) * 1024;
   auto load_k = [&](int hd, int c, bf8 (&ka)[2]) {
-    c = clampc(c);
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      int kt = kt_lo + 2 * c + t;
-      kt = kt < kt_hi ? kt : kt_hi - 1;
-      ka[t] = ldg_bf8(Kb + hd * hstride + (size_t)kt * 512, toff);
-    }
+    const __bf16* kp = kh0 + hd * hstride + (size_t)clampc(c) * 1024;
+    ka[0] = ldg_bf8(kp, toff);
+    ka[1] = ldg_bf8(kp + 512, toff);
   };
   auto load_v = [&](int hd, int c, bf8 (&va)[2]) {
-    c = clampc(c);
-    const __bf16* vu = VTb + hd * hstride + (size_t)((kt_lo >> 1) + c) * 1024;
-    va[0] = ldg_bf8(vu, toff);
-    va[1] = ldg_bf8(vu + 512, toff);
+    const __bf16* vp = vh0 + hd * hstride + (size_t)clampc(c) * 1024;
+    va[0] = ldg_bf8(vp, toff);
+    va[1] = ldg_bf8(vp + 512, toff);
   };
+  const int nfull = SELF ? 0 : (klim >> 5) - (kt_lo >> 1);  // cross-attention: chunks [0, nfull) hold 32 valid keys each
   auto chunk_is_interior = [&](int c) {
+    if (!SELF) return c < nfull;
     c = clampc(c);
     const int k0 = (kt_lo + 2 * c) << 4, k1 = k0 + 31;
     bool full = k1 < klim && (kt_lo + 2 * (c + 1)) <= kt_hi;
-    if (SELF && window >= 0) full = full && (k1 - m0 <= window) && (k0 - (m0 + 16 * NF - 1) >= -window);
+    if (window >= 0) full = full && (k1 - m0 <= window) && (k0 - (m0 + 16 * NF - 1) >= -window);
     return full;
   };
   auto mask_init = [&](int c, f4 (&S)[2][NF], const float (&vis)[NF]) {
@@ -337,9 +350,15 @@ EDTTS_DEV void attention16(QF&& qf, const __bf16* __restrict__ Kb, const __bf16*
   // step s = 0: the diagonal chunk; steps 1 .. nchunk-1: the other chunks in ascending order
   auto chunk_of = [&](int st) { return st >= nchunk ? nchunk - 1 : (st == 0 ? cdiag : (st <= cdiag ? st - 1 : st)); };
 
-  // K / V^T operands are double-buffered: the tiles of step s + 2 are requested while step s computes (with one wave per SIMD
-  // nothing else hides an L2 round trip: measured, with a one-step distance 40 % of the wave's cycles were s_waitcnt time)
-  bf8 KA0[2], VA0[2], KA1[2], VA1[2], q[NF];
+#ifndef EDTTS16_KVDEPTH
+#define EDTTS16_KVDEPTH 2
+#endif
+  // K / V^T operands are requested EDTTS16_KVDEPTH steps ahead into as many register buffers (2; 4 is a build option).  In-kernel
+  // stamps (scratch/stamps_bf16.py) show some steps waiting 1 000 - 2 000 cycles for their tiles at either depth, and the call time
+  // is the same (44.3 - 45.0 ms): the extra 32 registers of depth 4 cost in accumulator moves what the distance gains.
+  constexpr int KD = EDTTS16_KVDEPTH;
+  static_assert(KD == 2 || KD == 4, "K/V prefetch depth");
+  bf8 KA0[2], VA0[2], KA1[2], VA1[2], KA2[2], VA2[2], KA3[2], VA3[2], q[NF];
   auto prefetch = [&](int hd) {
 #pragma unroll
     for (int ft = 0; ft < NF; ++ft) q[ft] = qf(hd, ft);
@@ -347,6 +366,12 @@ EDTTS_DEV void attention16(QF&& qf, const __bf16* __restrict__ Kb, const __bf16*
     load_v(hd, chunk_of(0), VA0);
     load_k(hd, chunk_of(1), KA1);
     load_v(hd, chunk_of(1), VA1);
+    if (KD == 4) {
+      load_k(hd, chunk_of(2), KA2);
+      load_v(hd, chunk_of(2), VA2);
+      load_k(hd, chunk_of(3), KA3);
+      load_v(hd, chunk_of(3), VA3);
+    }
   };
   prefetch(0);
   for (int hd = 0; hd < C::HEADS; ++hd) {
@@ -358,6 +383,7 @@ EDTTS_DEV void attention16(QF&& qf, const __bf16* __restrict__ Kb, const __bf16*
       nm[ft] = 0.f;
     }
     auto step = [&](bool first, int c, int cnext2, bf8 (&KA)[2], bf8 (&VA)[2]) {
+      if (hd == 0) STAMPX(stamps, sidx++);
       f4 S[2][NF];
       if (chunk_is_interior(c)) {
         // the reference tile rides in as the C operand itself (written as S = NM; S = mfma(.., S) it cost 16 accumulator moves
@@ -374,6 +400,7 @@ EDTTS_DEV void attention16(QF&& qf, const __bf16* __restrict__ Kb, const __bf16*
           for (int ft = 0; ft < NF; ++ft) S[t][ft] = EDTTS_MFMA16(KA[t], q[ft], S[t][ft]);
       }
       load_k(hd, cnext2, KA);  // (re-reads a valid tile past the last step)
+      if (hd == 0) STAMPX(stamps, sidx++);
       f4 P[2][NF], ps[NF];
       auto lane_max = [&](int ft) {
         f4 mv = S[0][ft];
@@ -442,16 +469,32 @@ EDTTS_DEV void attention16(QF&& qf, const __bf16* __restrict__ Kb, const __bf16*
         lvec[ft] += ps[ft];
         pb[ft] = pack8(P[0][ft], P[1][ft]);
       }
+      if (hd == 0) STAMPX(stamps, sidx++);
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
         for (int ft = 0; ft < NF; ++ft) O[dt][ft] = EDTTS_MFMA16(VA[dt], pb[ft], O[dt][ft]);
       load_v(hd, cnext2, VA);
+      if (hd == 0) STAMPX(stamps, sidx++);
     };
-    step(true, chunk_of(0), chunk_of(2), KA0, VA0);
-    for (int st = 1; st < nchunk; st += 2) {
-      step(false, chunk_of(st), chunk_of(st + 2), KA1, VA1);
-      if (st + 1 < nchunk) step(false, chunk_of(st + 1), chunk_of(st + 3), KA0, VA0);
+    // (Measured alternatives, same device: groups of KD unconditional steps + a load-free tail so that hipcc's waitcnt pass sees
+    // the same number of outstanding loads on every path -- KD=2: 50.1 ms, KD=4: 46.2 ms against 45.7 ms for this loop; fully
+    // unrolled 16-step runs: 59 ms (spills); a skewed step that issues the score MFMAs of chunk s+1 ahead of the softmax of chunk s
+    // (matrix pipe under the VALU clump): 47.2 ms -- its 16 extra accumulators cost more in AGPR<->VGPR moves than the overlap
+    // gains.  The step is bound by its instruction count at one wave per SIMD, not by the distance of its loads.)
+    step(true, chunk_of(0), chunk_of(KD), KA0, VA0);
+    if (KD == 2) {
+      for (int st = 1; st < nchunk; st += 2) {
+        step(false, chunk_of(st), chunk_of(st + 2), KA1, VA1);
+        if (st + 1 < nchunk) step(false, chunk_of(st + 1), chunk_of(st + 3), KA0, VA0);
+      }
+    } else {
+      for (int st = 1; st < nchunk; st += 4) {
+        step(false, chunk_of(st), chunk_of(st + 4), KA1, VA1);
+        if (st + 1 < nchunk) step(false, chunk_of(st + 1), chunk_of(st + 5), KA2, VA2);
+        if (st + 2 < nchunk) step(false, chunk_of(st + 2), chunk_of(st + 6), KA3, VA3);
+        if (st + 3 < nchunk) step(false, chunk_of(st + 3), chunk_of(st + 7), KA0, VA0);
+      }
     }
     bf8 ob[NF];
 #pragma unroll
@@ -572,11 +615,6 @@ __global__ __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) void k_prologue1
 // =========================================================================================================
 // transformer layer kernel (bf16 contractions)
 // =========================================================================================================
-#ifdef EDTTS_STAMPS
-#define STAMP16(i) do { if (a.stamps && blockIdx.x == 0 && threadIdx.x == 0) a.stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define STAMP16(i) do { } while (0)
-#endif
 template <class C, int TAIL>
 __global__ __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) void k_layer16(KArgs a) {
   extern __shared__ __attribute__((aligned(16))) f4 ring_lds16[];
@@ -646,7 +684,11 @@ __global__ __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) void k_layer16(K
       return r;
     };
     attention16<C, false>(qf, reinterpret_cast<const __bf16*>(a.kc) + (size_t)b * a.Sp * C::H,
-                          reinterpret_cast<const __bf16*>(a.vcT) + (size_t)b * C::H * a.Sp, a.Sp, a.S, -1, m0, lane, ring, h);
+                          reinterpret_cast<const __bf16*>(a.vcT) + (size_t)b * C::H * a.Sp, a.Sp, a.S, -1, m0, lane, ring, h
+#ifdef EDTTS_STAMPS
+                          , a.stamps ? a.stamps + 8 : nullptr
+#endif
+                          );
   }
   STAMP16(3);
   // ---- x = x + ffn(norm3(x, cond))   (transformer.py:154-158, :13-49) ----

@@ -1510,7 +1510,7 @@ struct Launcher16 {
         a.c_s1m = coef[0]; a.c_sab = coef[1]; a.c_sabp = coef[2]; a.c_dir = coef[3];
       }
 #ifdef EDTTS_STAMPS
-      a.stamps = g_stamps_fwd ? g_stamps_fwd + 32 * l : nullptr;
+      a.stamps = g_stamps_fwd ? g_stamps_fwd + 128 * l : nullptr;
 #endif
 #define EDTTS_LAUNCH16(TL) PROF_LAUNCH(st, hipLaunchKernelGGL((edtts16::k_layer16<C, TL>), dim3(g), dim3(C::THREADS), C::LDS_BYTES, st, a))
       switch (t_eff) {

@@ -12,16 +12,25 @@ gen = torch.Generator().manual_seed(0)
 B, T, S = 256, 1024, 512
 x = torch.randn(B, T, 80, generator=gen).cuda(); sem = torch.randint(0, 512, (B, S), generator=gen).cuda()
 t = torch.full((B,), 500).cuda(); si = torch.zeros(B, dtype=torch.long).cuda()
-buf = torch.zeros(32 * 8, dtype=torch.int64, device="cuda")
+buf = torch.zeros(128 * 8, dtype=torch.int64, device="cuda")
 L = native.lib()
 L.edtts_debug_set_stamps.argtypes = [C.c_void_p]
 for _ in range(2): dec(x, t, sem, si)
 L.edtts_debug_set_stamps(buf.data_ptr())
 dec(x, t, sem, si); torch.cuda.synchronize()
-st = buf.cpu().view(8, 32)[:, :7]
+full = buf.cpu().view(8, 128)
+st = full[:, :7]
 names = ["self-attn (8 heads: steps + proj phase)", "norm2 + q_proj (8 phases)", "cross-attn (8 heads x 16 steps + out_proj phase)", "norm3 + FFN (48 phases)", "tail: store h, norm, QKV (24 phases)", "drain"]
 for l in (1, 4):
     d = (st[l, 1:] - st[l, :-1]).tolist()
     tot = int(st[l, 6] - st[l, 0])
     print(f"layer {l}: total {tot} memtime ticks (100 MHz constant clock? see below)")
     for n, v in zip(names, d): print(f"   {n:55s} {v:9d}  {100.0*v/tot:5.1f} %")
+
+# fine-grained: cross-attention head 0 of layer 4, 4 stamps per step: [start | after QK issue + K request | after softmax + pack | after PV issue + V request]
+fs = full[4, 8:8 + 4 * 16].view(16, 4)
+print("cross-attention head 0, per step: QK+loads | softmax | PV+loads | (gap to next step start)")
+for i in range(16):
+    a, b, c, d = fs[i].tolist()
+    nxt = fs[i + 1, 0].item() if i < 15 else d
+    print(f"  step {i:2d}: {b-a:6d} {c-b:6d} {d-c:6d} {nxt-d:6d}   total {nxt-a}")
