@@ -263,9 +263,11 @@ EDTTS_DEV void layer_norm_pack(const f4 (&x)[C::HT][C::NF], const float* __restr
 //   !SELF: keys are the S context tokens, no mask (layers/mla.py:158-179)
 // qf(hd, ft): this lane's q operand (8 bf16) of head hd, query tile ft.
 // ---------------------------------------------------------------------------------------------------------
-template <class C, bool SELF, class QF>
+// sink(hd, ob): consumes head hd's normalised output (the lane's 8 bf16 per query tile = the B operand of the output projection):
+// the fused layer kernel feeds it straight to the projection (ktile16), the stand-alone attention kernel stores it.
+template <class C, bool SELF, class QF, class SINK>
 EDTTS_DEV void attention16(QF&& qf, const __bf16* __restrict__ Kb, const __bf16* __restrict__ VTb, int kpad, int nkeys,
-                           int window, int m0, int lane, Ring16<C>& ring, f4 (&delta)[C::HT][C::NF], unsigned long long* stamps = nullptr) {
+                           int window, int m0, int lane, SINK&& sink, unsigned long long* stamps = nullptr) {
   constexpr int NF = C::NF;
   int sidx = 0;  // (EDTTS_STAMPS diagnostic builds: fine-grained stamps of head 0)
   (void)sidx; (void)stamps;
@@ -504,7 +506,7 @@ EDTTS_DEV void attention16(QF&& qf, const __bf16* __restrict__ Kb, const __bf16*
       ob[ft] = pack8(O[0][ft] * inv, O[1][ft] * inv);
     }
     if (hd + 1 < C::HEADS) prefetch(hd + 1);
-    ktile16<C::HT>(ring, ob, delta);  // delta += Wo[:, head hd] . O
+    sink(hd, ob);
   }
 }
 
@@ -615,7 +617,41 @@ __global__ __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) void k_prologue1
 // =========================================================================================================
 // transformer layer kernel (bf16 contractions)
 // =========================================================================================================
-template <class C, int TAIL>
+// ---------------------------------------------------------------------------------------------------------
+// Stand-alone attention (split layer): the same attention16 as the fused kernel, but with nothing else live -- no residual tile,
+// no weight ring, no LDS -- so that several waves share a SIMD and hide each other's softmax / load latency.  One wave = 32 query
+// frames, all heads in turn; q rows in, normalised O rows out (both [frame][H] bf16, slot order inside a head).
+// ---------------------------------------------------------------------------------------------------------
+#ifndef EDTTS16_ATT_OCC
+#define EDTTS16_ATT_OCC 2
+#endif
+template <class C, bool SELF>
+__global__ __launch_bounds__(C::THREADS, EDTTS16_ATT_OCC) void k_attn16(KArgs a) {
+  const TileId tl = wave_tile(a.B, a.Tp, C::WAVES, C::WF);
+  if (!tl.valid) return;  // (no block-level synchronisation in this kernel)
+  constexpr int NF = C::NF;
+  const int lane = threadIdx.x & 63, fq = lane & 15, g = lane >> 4;
+  const int b = tl.b, m0 = tl.m0;
+  const size_t rowbase = (size_t)b * a.Tp + m0 + fq;
+  const __bf16* qrow = reinterpret_cast<const __bf16*>(a.attn_q) + rowbase * C::H + 8 * g;
+  __bf16* orow = reinterpret_cast<__bf16*>(a.attn_o) + rowbase * C::H + 8 * g;
+  auto qf = [&](int hd, int ft) { return *reinterpret_cast<const bf8*>(qrow + (size_t)ft * 16 * C::H + hd * C::DH); };
+  auto sink = [&](int hd, const bf8 (&ob)[NF]) {
+#pragma unroll
+    for (int ft = 0; ft < NF; ++ft) *reinterpret_cast<bf8*>(orow + (size_t)ft * 16 * C::H + hd * C::DH) = ob[ft];
+  };
+  if (SELF)
+    attention16<C, true>(qf, reinterpret_cast<const __bf16*>(a.k) + (size_t)b * a.Tp * C::H,
+                         reinterpret_cast<const __bf16*>(a.vT) + (size_t)b * C::H * a.Tp, a.Tp, a.T, a.window, m0, lane, sink);
+  else
+    attention16<C, false>(qf, reinterpret_cast<const __bf16*>(a.kc) + (size_t)b * a.Sp * C::H,
+                          reinterpret_cast<const __bf16*>(a.vcT) + (size_t)b * C::H * a.Sp, a.Sp, a.S, -1, m0, lane, sink);
+}
+
+// PART16_ALL: the whole layer in one launch.  Split layer: k_attn16<self> | PART16_MID (self out-projection, norm2, cross q) |
+// k_attn16<cross> | PART16_POST (cross out-projection, FFN, tail) -- same arithmetic in the same order, bitwise the same result.
+enum { PART16_ALL = 0, PART16_MID = 1, PART16_POST = 2 };
+template <class C, int TAIL, int PART = PART16_ALL>
 __global__ __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) void k_layer16(KArgs a) {
   extern __shared__ __attribute__((aligned(16))) f4 ring_lds16[];
   const TileId tl = wave_tile(a.B, a.Tp, C::WAVES, C::WF);
@@ -624,7 +660,12 @@ __global__ __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) void k_layer16(K
   const int b = tl.b, m0 = tl.m0;
   const size_t rowbase = (size_t)b * a.Tp + m0 + fq;
   Ring16<C> ring;
-  ring.start(a.stream, ring_lds16, __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane);
+  // weight stream of a layer: self out-projection (HEADS k-tiles of HT fragments) | cross q (KT pairs of n-tiles over KT k-tiles) |
+  // cross out-projection | FFN | tail; a fragment = 16 x 32 bf16 = 256 floats
+  constexpr int kPostStreamFloats = (C::HEADS * C::HT + 2 * C::KT * C::KT) * 256;
+  static_assert((C::HEADS * C::HT + 2 * C::KT * C::KT) % C::PH == 0, "the POST part starts on a phase boundary");
+  ring.start(PART == PART16_POST ? a.stream + kPostStreamFloats : a.stream, ring_lds16,
+             __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane);
   // Small parameter vectors that are read INSIDE the streaming loops go through LDS: an ordinary global load consumed while
   // ring DMAs are in flight makes hipcc's waitcnt pass emit s_waitcnt vmcnt(0) (it cannot count the DMAs of earlier loop
   // iterations), which drains the whole prefetch ring once per phase -- measured: 2 800 cycles per 512-cycle phase.
@@ -642,21 +683,65 @@ __global__ __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) void k_layer16(K
   float* const hp = a.h + rowbase * C::H + 4 * g;
 #pragma unroll
   for (int nt = 0; nt < C::HT; ++nt) {
-    const f4 pb = ldg4(a.proj_b + 16 * nt + 4 * g);
+    const f4 pb = PART == PART16_POST ? splat(0.f) : ldg4(a.proj_b + 16 * nt + 4 * g);
 #pragma unroll
     for (int ft = 0; ft < NF; ++ft) h[nt][ft] = ldg4(hp + 16 * nt + (size_t)ft * 16 * C::H) + pb;
   }
+  // split layer: this wave's attention output rows (all heads), fetched and WAITED FOR before the streaming loop (a global load
+  // consumed inside it would make hipcc drain the ring with vmcnt(0) every phase), then projected head by head
+  auto project_attn_rows = [&]() {
+    bf8 oa[C::HEADS][NF];
+    const __bf16* orow = reinterpret_cast<const __bf16*>(a.attn_o) + rowbase * C::H + 8 * g;
+#pragma unroll
+    for (int hd = 0; hd < C::HEADS; ++hd)
+#pragma unroll
+      for (int ft = 0; ft < NF; ++ft) {
+        oa[hd][ft] = *reinterpret_cast<const bf8*>(orow + (size_t)ft * 16 * C::H + hd * C::DH);
+      }
+#pragma unroll
+    for (int hd = 0; hd < C::HEADS; ++hd)
+#pragma unroll
+      for (int ft = 0; ft < NF; ++ft) asm volatile("" : "+v"(oa[hd][ft]));
+#pragma unroll
+    for (int hd = 0; hd < C::HEADS; ++hd) ktile16<C::HT>(ring, oa[hd], h);
+  };
   STAMP16(0);
   // ---- x = x + attn(norm1(x, cond))   (transformer.py:142-146; q / k / v^T were produced by the previous kernel) ----
-  {
+  if (PART == PART16_MID) project_attn_rows();
+  if (PART == PART16_ALL) {
     const __bf16* qrow = reinterpret_cast<const __bf16*>(a.q) + rowbase * C::H + 8 * g;
     auto qf = [&](int hd, int ft) { return *reinterpret_cast<const bf8*>(qrow + (size_t)ft * 16 * C::H + hd * C::DH); };
     attention16<C, true>(qf, reinterpret_cast<const __bf16*>(a.k) + (size_t)b * a.Tp * C::H,
-                         reinterpret_cast<const __bf16*>(a.vT) + (size_t)b * C::H * a.Tp, a.Tp, a.T, a.window, m0, lane, ring, h);
+                         reinterpret_cast<const __bf16*>(a.vT) + (size_t)b * C::H * a.Tp, a.Tp, a.T, a.window, m0, lane,
+                         [&](int, const bf8 (&ob)[NF]) { ktile16<C::HT>(ring, ob, h); });  // h += Wo[:, head] . O
   }
   STAMP16(1);
   // ---- x = x + cross_attn(norm2(x), context)   (transformer.py:151, mla.py:118-194) ----
-  {
+  if (PART == PART16_POST) project_attn_rows();
+  if (PART == PART16_MID) {
+    // cross q of this wave's rows -> memory, residual -> memory; the cross-attention kernel and PART16_POST take over
+    bf8 hn[C::KT][NF];
+    rms_norm_pack<C>(h, a.n2w, nullptr, g, hn);
+    __bf16* qrow = reinterpret_cast<__bf16*>(a.qc_out) + rowbase * C::H + 8 * g;
+    for (int p = 0; p < C::KT; ++p) {
+      f4 acc[2][NF];
+#pragma unroll
+      for (int ft = 0; ft < NF; ++ft) acc[0][ft] = acc[1][ft] = splat(0.f);
+      gemm16_pair<C::KT, false>(ring, hn, acc[0], acc[1]);
+      if (valid)
+#pragma unroll
+        for (int ft = 0; ft < NF; ++ft) *reinterpret_cast<f4*>(qrow + (size_t)ft * 16 * C::H + p * C::DH) = as_f4(pack8(acc[0][ft], acc[1][ft]));
+    }
+    if (valid) {
+#pragma unroll
+      for (int nt = 0; nt < C::HT; ++nt)
+#pragma unroll
+        for (int ft = 0; ft < NF; ++ft) stg4(hp + 16 * nt + (size_t)ft * 16 * C::H, h[nt][ft]);
+    }
+    ring.drain();
+    return;
+  }
+  if (PART == PART16_ALL) {
     bf8 qx[C::KT][NF];
     {
       bf8 hn[C::KT][NF];
@@ -684,7 +769,8 @@ __global__ __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) void k_layer16(K
       return r;
     };
     attention16<C, false>(qf, reinterpret_cast<const __bf16*>(a.kc) + (size_t)b * a.Sp * C::H,
-                          reinterpret_cast<const __bf16*>(a.vcT) + (size_t)b * C::H * a.Sp, a.Sp, a.S, -1, m0, lane, ring, h
+                          reinterpret_cast<const __bf16*>(a.vcT) + (size_t)b * C::H * a.Sp, a.Sp, a.S, -1, m0, lane,
+                          [&](int, const bf8 (&ob)[NF]) { ktile16<C::HT>(ring, ob, h); }
 #ifdef EDTTS_STAMPS
                           , a.stamps ? a.stamps + 8 : nullptr
 #endif

@@ -386,6 +386,10 @@ struct KArgs {
   const float *q, *k, *vT;
   float *q_out, *k_out, *vT_out;
   float *kc, *vcT;  // cross K / V^T cache: kernel-specific base (k_ctx: whole cache; k_layer: this layer's slice)
+  // bf16 split layer (edtts_bf16.h, k_attn16 / k_layer16<.., PART16_MID|POST>): attention input q rows, attention output rows,
+  // where the middle kernel leaves the cross-attention q
+  const float* attn_q;
+  float *attn_o, *qc_out;
   const int64_t* sem_idx;
   const float* sem_feat;
   const float* cond;  // row base: [L][2][2H] per row
@@ -1440,6 +1444,16 @@ struct Launcher16 {
     HIP_TRY(hipFuncSetAttribute((const void*)edtts16::k_layer16<C, TAIL_DDPM>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     HIP_TRY(hipFuncSetAttribute((const void*)edtts16::k_layer16<C, TAIL_LMS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     HIP_TRY(hipFuncSetAttribute((const void*)edtts16::k_layer16<C, TAIL_VPRED>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+#if EDTTS16_SPLIT_BUILD
+    using namespace edtts16;
+    HIP_TRY(hipFuncSetAttribute((const void*)k_layer16<C, TAIL_QKV, PART16_MID>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    HIP_TRY(hipFuncSetAttribute((const void*)k_layer16<C, TAIL_QKV, PART16_POST>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    HIP_TRY(hipFuncSetAttribute((const void*)k_layer16<C, TAIL_EPS, PART16_POST>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    HIP_TRY(hipFuncSetAttribute((const void*)k_layer16<C, TAIL_DDIM, PART16_POST>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    HIP_TRY(hipFuncSetAttribute((const void*)k_layer16<C, TAIL_DDPM, PART16_POST>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    HIP_TRY(hipFuncSetAttribute((const void*)k_layer16<C, TAIL_LMS, PART16_POST>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    HIP_TRY(hipFuncSetAttribute((const void*)k_layer16<C, TAIL_VPRED, PART16_POST>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+#endif
     done[dev] = true;
     return EDTTS_OK;
   }
@@ -1512,7 +1526,28 @@ struct Launcher16 {
 #ifdef EDTTS_STAMPS
       a.stamps = g_stamps_fwd ? g_stamps_fwd + 128 * l : nullptr;
 #endif
+#if EDTTS16_SPLIT_BUILD
+      // Split layer (a -DEDTTS16_SPLIT_BUILD=1 library with EDTTS16_SPLIT=1 in the environment; measured and not shipped, DESIGN.md
+      // 4.5): attention in its own launches at three waves per SIMD.  No extra buffers: within a layer the q / O rows live in the
+      // two q sets (in: q -> cross q; out: O of the self-attention -> O of the cross-attention -> the next layer's q, each wave
+      // touching only its own rows).  Bitwise the same results as the fused launch (scratch/split_probe.py).
+      static const bool split = [] { const char* e = getenv("EDTTS16_SPLIT"); return e && e[0] == '1'; }();
+      if (split) {
+        a.attn_q = a.q; a.attn_o = a.q_out;
+        PROF_LAUNCH(st, hipLaunchKernelGGL((edtts16::k_attn16<C, true>), dim3(g), dim3(C::THREADS), 0, st, a));
+        a.qc_out = const_cast<float*>(a.q);
+        PROF_LAUNCH(st, hipLaunchKernelGGL((edtts16::k_layer16<C, TAIL_QKV, edtts16::PART16_MID>), dim3(g), dim3(C::THREADS), C::LDS_BYTES, st, a));
+        a.attn_q = a.q;
+        PROF_LAUNCH(st, hipLaunchKernelGGL((edtts16::k_attn16<C, false>), dim3(g), dim3(C::THREADS), 0, st, a));
+      }
+#define EDTTS_LAUNCH16(TL)                                                                                                          \
+  do {                                                                                                                              \
+    if (split) PROF_LAUNCH(st, hipLaunchKernelGGL((edtts16::k_layer16<C, TL, edtts16::PART16_POST>), dim3(g), dim3(C::THREADS), C::LDS_BYTES, st, a)); \
+    else PROF_LAUNCH(st, hipLaunchKernelGGL((edtts16::k_layer16<C, TL>), dim3(g), dim3(C::THREADS), C::LDS_BYTES, st, a));            \
+  } while (0)
+#else
 #define EDTTS_LAUNCH16(TL) PROF_LAUNCH(st, hipLaunchKernelGGL((edtts16::k_layer16<C, TL>), dim3(g), dim3(C::THREADS), C::LDS_BYTES, st, a))
+#endif
       switch (t_eff) {
         case TAIL_QKV: EDTTS_LAUNCH16(TAIL_QKV); break;
         case TAIL_EPS: EDTTS_LAUNCH16(TAIL_EPS); break;
