@@ -36,5 +36,15 @@ int main() {
     printf("blocks %4d (%.1f waves/SIMD): %.3f ms, %.1f TFLOP/s = %.3f of 157.3; per-SIMD MFMA issue interval %.2f cycles at 2.4 GHz\n",
            blocks, blocks * 4 / 1024.0, ms, fl / ms / 1e9, fl / ms / 1e9 / 157.3, ms * 1e-3 * 2.4e9 / (mf / 1024.0));
   }
+  // one wave per SIMD: does the number of independent accumulator chains matter?
+  auto one = [&](auto kern, int chains) {
+    const int iters = 20000, blocks = 256;
+    kern<<<blocks, 256>>>(out, 1000); CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0)); kern<<<blocks, 256>>>(out, iters); CK(hipEventRecord(e1)); CK(hipDeviceSynchronize());
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    const double mf = (double)blocks * 4 * iters * 8 * chains;
+    printf("1 wave/SIMD, %d chains: issue interval %.2f cycles at 2.4 GHz\n", chains, ms * 1e-3 * 2.4e9 / (mf / 1024.0));
+  };
+  one(k<2>, 2); one(k<8>, 8); one(k<16>, 16);
   return 0;
 }
