@@ -1446,6 +1446,9 @@ struct Launcher16 {
     HIP_TRY(hipFuncSetAttribute((const void*)edtts16::k_layer16<C, TAIL_VPRED>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
 #if EDTTS16_SPLIT_BUILD
     using namespace edtts16;
+    // (occupancy experiment: EDTTS16_ATT_LDS bytes of unused dynamic LDS per attention block limit the blocks per CU)
+    HIP_TRY(hipFuncSetAttribute((const void*)k_attn16<C, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIP_TRY(hipFuncSetAttribute((const void*)k_attn16<C, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIP_TRY(hipFuncSetAttribute((const void*)k_layer16<C, TAIL_QKV, PART16_MID>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     HIP_TRY(hipFuncSetAttribute((const void*)k_layer16<C, TAIL_QKV, PART16_POST>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     HIP_TRY(hipFuncSetAttribute((const void*)k_layer16<C, TAIL_EPS, PART16_POST>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -1532,13 +1535,14 @@ struct Launcher16 {
       // two q sets (in: q -> cross q; out: O of the self-attention -> O of the cross-attention -> the next layer's q, each wave
       // touching only its own rows).  Bitwise the same results as the fused launch (scratch/split_probe.py).
       static const bool split = [] { const char* e = getenv("EDTTS16_SPLIT"); return e && e[0] == '1'; }();
+      static const int att_lds = [] { const char* e = getenv("EDTTS16_ATT_LDS"); return e ? atoi(e) : 0; }();
       if (split) {
         a.attn_q = a.q; a.attn_o = a.q_out;
-        PROF_LAUNCH(st, hipLaunchKernelGGL((edtts16::k_attn16<C, true>), dim3(g), dim3(C::THREADS), 0, st, a));
+        PROF_LAUNCH(st, hipLaunchKernelGGL((edtts16::k_attn16<C, true>), dim3(g), dim3(C::THREADS), att_lds, st, a));
         a.qc_out = const_cast<float*>(a.q);
         PROF_LAUNCH(st, hipLaunchKernelGGL((edtts16::k_layer16<C, TAIL_QKV, edtts16::PART16_MID>), dim3(g), dim3(C::THREADS), C::LDS_BYTES, st, a));
         a.attn_q = a.q;
-        PROF_LAUNCH(st, hipLaunchKernelGGL((edtts16::k_attn16<C, false>), dim3(g), dim3(C::THREADS), 0, st, a));
+        PROF_LAUNCH(st, hipLaunchKernelGGL((edtts16::k_attn16<C, false>), dim3(g), dim3(C::THREADS), att_lds, st, a));
       }
 #define EDTTS_LAUNCH16(TL)                                                                                                          \
   do {                                                                                                                              \
