@@ -64,9 +64,18 @@ struct Cfg16 {
   // Weight stream: every GEMM unit of the kernels (an n-tile pair over all k-tiles, or one k-tile over all n-tiles) consumes
   // exactly PH = HT fragments (1 KiB each) -- one PHASE.  The block shares one LDS ring of NS phase slots (see LdsRing).
   static constexpr int PH = HT;                 // fragments per phase
-  static constexpr int NS = (NF == 1 && WAVES == 4) ? 4 : 6;  // ring slots (phases): NS - 1 phases are in flight ahead of the consumers
+#ifndef EDTTS16_QLDS
+#define EDTTS16_QLDS 1   // cross-attention q of all heads parked in LDS (1) instead of 64 registers (0)
+#endif
+  // cross-attention q operands of a wave's frames, all heads: [head][frame tile][lane] x 16 B -- written once after the q
+  // projection, read back head by head (64 registers less during the cross-attention; the ring gives up one slot for it)
+  static constexpr int QLDS_BYTES = EDTTS16_QLDS ? WAVES * HEADS * NF * 1024 : 0;
+  static constexpr int NS_MAX = (NF == 1 && WAVES == 4) ? 4 : 6;  // ring slots (phases): NS - 1 phases are in flight ahead of the consumers
   static constexpr int PARAM_FLOATS = 4 * H + MEL;  // FFN up bias (stream order) + out_proj bias, staged in LDS (see k_layer16)
-  static constexpr int LDS_BYTES = NS * PH * 1024 + PARAM_FLOATS * 4;
+  static constexpr int NS_FIT = (160 * 1024 - PARAM_FLOATS * 4 - QLDS_BYTES) / (PH * 1024);
+  static constexpr int NS = NS_FIT < NS_MAX ? NS_FIT : NS_MAX;
+  static constexpr int LDS_BYTES = NS * PH * 1024 + PARAM_FLOATS * 4 + QLDS_BYTES;
+  static_assert(NS >= 3, "ring depth");
   static_assert(DH == 32, "the bf16 instance is built for head_dim 32 (one MFMA k-tile per head)");
   static_assert(NF == 1 || NF == 2, "frame tiles per wave");
   static_assert(H % 64 == 0 && MEL % 16 == 0 && PH % WAVES == 0 && LDS_BYTES <= 160 * 1024, "dims vs ring");
@@ -352,6 +361,177 @@ EDTTS_DEV void attention16(QF&& qf, const __bf16* __restrict__ Kb, const __bf16*
   // step s = 0: the diagonal chunk; steps 1 .. nchunk-1: the other chunks in ascending order
   auto chunk_of = [&](int st) { return st >= nchunk ? nchunk - 1 : (st == 0 ? cdiag : (st <= cdiag ? st - 1 : st)); };
 
+#ifndef EDTTS16_HP
+#define EDTTS16_HP 2   // heads per attention step (1: the single-head step below)
+#endif
+#if EDTTS16_HP == 2
+  // TWO HEADS PER STEP.  Both heads of a pair walk the same chunks with the same masks, so the interior test, the mask predicates,
+  // the loop control and the rescale branch are paid once per 2 x 16 scores, and the step holds two independent
+  // MFMA -> exp2 -> pack -> MFMA chains for the scheduler to interleave: with one wave per SIMD nothing else hides their latencies
+  // (stand-alone attention, 4.5: a second instruction stream per SIMD is worth 1.45x).
+  static_assert(C::HEADS % 2 == 0, "head pairs");
+  constexpr int HP = 2;
+  bf8 KA0[HP][2], VA0[HP][2], KA1[HP][2], VA1[HP][2], q[HP][NF];
+  auto prefetch = [&](int hd) {
+#pragma unroll
+    for (int h = 0; h < HP; ++h) {
+#pragma unroll
+      for (int ft = 0; ft < NF; ++ft) q[h][ft] = qf(hd + h, ft);
+      load_k(hd + h, chunk_of(0), KA0[h]);
+      load_v(hd + h, chunk_of(0), VA0[h]);
+      load_k(hd + h, chunk_of(1), KA1[h]);
+      load_v(hd + h, chunk_of(1), VA1[h]);
+    }
+  };
+  prefetch(0);
+  for (int hd = 0; hd < C::HEADS; hd += HP) {
+    f4 O[HP][2][NF], lvec[HP][NF], NM[HP][NF];
+    float nm[HP][NF];
+#pragma unroll
+    for (int h = 0; h < HP; ++h)
+#pragma unroll
+      for (int ft = 0; ft < NF; ++ft) {
+        O[h][0][ft] = O[h][1][ft] = lvec[h][ft] = NM[h][ft] = splat(0.f);
+        nm[h][ft] = 0.f;
+      }
+    auto step = [&](bool first, int c, int cnext2, bf8 (&KA)[HP][2], bf8 (&VA)[HP][2]) {
+      f4 S[HP][2][NF];
+      if (chunk_is_interior(c)) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int ft = 0; ft < NF; ++ft)
+#pragma unroll
+            for (int h = 0; h < HP; ++h) S[h][t][ft] = EDTTS_MFMA16(KA[h][t], q[h][ft], NM[h][ft]);
+      } else {
+        // the visibility predicates are the pair's; each head selects its own reference point
+        const int cc = clampc(c);
+        const int k0 = (kt_lo + 2 * cc) << 4;
+#pragma unroll
+        for (int ft = 0; ft < NF; ++ft) {
+          const int d0 = k0 + 4 * g - (m0 + 16 * ft + fq) - lo_d[ft];
+          const unsigned sp = span[ft] >= 0 ? (unsigned)span[ft] : 0u;
+          const int bias = span[ft] >= 0 ? 0 : (1 << 30);
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const bool vis = (unsigned)(d0 + bias + 16 * t + r) <= sp;
+#pragma unroll
+              for (int h = 0; h < HP; ++h) S[h][t][ft][r] = vis ? nm[h][ft] : NEG_INF;
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int ft = 0; ft < NF; ++ft)
+#pragma unroll
+            for (int h = 0; h < HP; ++h) S[h][t][ft] = EDTTS_MFMA16(KA[h][t], q[h][ft], S[h][t][ft]);
+      }
+#pragma unroll
+      for (int h = 0; h < HP; ++h) load_k(hd + h, cnext2, KA[h]);  // (re-reads a valid tile past the last step)
+      f4 P[HP][2][NF], ps[HP][NF];
+      auto exp_and_sum = [&](int h, int ft, float m) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) P[h][t][ft][r] = fast_exp2(S[h][t][ft][r] - m);
+        ps[h][ft] = P[h][0][ft] + P[h][1][ft];
+      };
+      if (first) {
+#pragma unroll
+        for (int h = 0; h < HP; ++h)
+#pragma unroll
+          for (int ft = 0; ft < NF; ++ft) {
+            f4 mv = S[h][0][ft];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mv[r] = fmaxf(mv[r], S[h][1][ft][r]);
+            const float gm = group_max(hmax(mv));
+            const float m = gm > -1e30f ? gm : 0.f;
+            nm[h][ft] = -m;
+            NM[h][ft] = splat(-m);
+            exp_and_sum(h, ft, m);
+          }
+      } else {
+        const float lim = 4294967296.f;  // 2^32 (kDefer)
+        bool over = false;
+#pragma unroll
+        for (int h = 0; h < HP; ++h)
+#pragma unroll
+          for (int ft = 0; ft < NF; ++ft) {
+            exp_and_sum(h, ft, 0.f);
+            over = over || !(hsum(ps[h][ft]) <= lim);
+          }
+        if (__any(over)) {
+          // rare path (inputs through a volatile asm: see the single-head step)
+          f4 T[HP][2][NF];
+#pragma unroll
+          for (int h = 0; h < HP; ++h)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+              for (int ft = 0; ft < NF; ++ft) {
+                T[h][t][ft] = S[h][t][ft];
+                asm volatile("" : "+v"(T[h][t][ft]));
+              }
+#pragma unroll
+          for (int h = 0; h < HP; ++h)
+#pragma unroll
+            for (int ft = 0; ft < NF; ++ft) {
+              f4 mv = T[h][0][ft];
+#pragma unroll
+              for (int r = 0; r < 4; ++r) mv[r] = fmaxf(mv[r], T[h][1][ft][r]);
+              const float dl = fmaxf(0.f, group_max(hmax(mv)));
+              const float alpha = fast_exp2(-dl);
+              nm[h][ft] -= dl;
+              NM[h][ft] = splat(nm[h][ft]);
+              lvec[h][ft] *= alpha;
+              O[h][0][ft] *= alpha;
+              O[h][1][ft] *= alpha;
+#pragma unroll
+              for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) P[h][t][ft][r] = fast_exp2(T[h][t][ft][r] - dl);
+              ps[h][ft] = P[h][0][ft] + P[h][1][ft];
+            }
+        }
+      }
+      bf8 pb[HP][NF];
+#pragma unroll
+      for (int h = 0; h < HP; ++h)
+#pragma unroll
+        for (int ft = 0; ft < NF; ++ft) {
+          lvec[h][ft] += ps[h][ft];
+          pb[h][ft] = pack8(P[h][0][ft], P[h][1][ft]);
+        }
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int ft = 0; ft < NF; ++ft)
+#pragma unroll
+          for (int h = 0; h < HP; ++h) O[h][dt][ft] = EDTTS_MFMA16(VA[h][dt], pb[h][ft], O[h][dt][ft]);
+#pragma unroll
+      for (int h = 0; h < HP; ++h) load_v(hd + h, cnext2, VA[h]);
+    };
+    step(true, chunk_of(0), chunk_of(2), KA0, VA0);
+    for (int st = 1; st < nchunk; st += 2) {
+      step(false, chunk_of(st), chunk_of(st + 2), KA1, VA1);
+      if (st + 1 < nchunk) step(false, chunk_of(st + 1), chunk_of(st + 3), KA0, VA0);
+    }
+    bf8 ob[HP][NF];
+#pragma unroll
+    for (int h = 0; h < HP; ++h)
+#pragma unroll
+      for (int ft = 0; ft < NF; ++ft) {
+        const float lt = group_sum(hsum(lvec[h][ft]));
+        const float inv = lt > 0.f ? 1.0f / lt : 0.f;
+        ob[h][ft] = pack8(O[h][0][ft] * inv, O[h][1][ft] * inv);
+      }
+    if (hd + HP < C::HEADS) prefetch(hd + HP);
+#pragma unroll
+    for (int h = 0; h < HP; ++h) sink(hd + h, ob[h]);
+  }
+#else
 #ifndef EDTTS16_KVDEPTH
 #define EDTTS16_KVDEPTH 2
 #endif
@@ -508,6 +688,7 @@ EDTTS_DEV void attention16(QF&& qf, const __bf16* __restrict__ Kb, const __bf16*
     if (hd + 1 < C::HEADS) prefetch(hd + 1);
     sink(hd, ob);
   }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -742,6 +923,24 @@ __global__ __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) void k_layer16(K
     return;
   }
   if (PART == PART16_ALL) {
+#if EDTTS16_QLDS
+    f4* const qlds = ring_lds16 + C::NS * C::PH * 64 + (C::PARAM_FLOATS + 3) / 4 +
+                     (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * C::HEADS * NF) * 64 + lane;
+    {
+      bf8 hn[C::KT][NF];
+      rms_norm_pack<C>(h, a.n2w, nullptr, g, hn);
+      for (int p = 0; p < C::KT; ++p) {
+        f4 acc[2][NF];
+#pragma unroll
+        for (int ft = 0; ft < NF; ++ft) acc[0][ft] = acc[1][ft] = splat(0.f);
+        gemm16_pair<C::KT, false>(ring, hn, acc[0], acc[1]);
+#pragma unroll
+        for (int ft = 0; ft < NF; ++ft) qlds[(p * NF + ft) * 64] = as_f4(pack8(acc[0][ft], acc[1][ft]));
+      }
+    }
+    STAMP16(2);
+    auto qf = [&](int hd, int ft) { return as_bf8(qlds[(hd * NF + ft) * 64]); };
+#else
     bf8 qx[C::KT][NF];
     {
       bf8 hn[C::KT][NF];
@@ -768,6 +967,7 @@ __global__ __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) void k_layer16(K
         if (pp == hd) r = qx[pp][ft];
       return r;
     };
+#endif
     attention16<C, false>(qf, reinterpret_cast<const __bf16*>(a.kc) + (size_t)b * a.Sp * C::H,
                           reinterpret_cast<const __bf16*>(a.vcT) + (size_t)b * C::H * a.Sp, a.Sp, a.S, -1, m0, lane,
                           [&](int, const bf8 (&ob)[NF]) { ktile16<C::HT>(ring, ob, h); }
