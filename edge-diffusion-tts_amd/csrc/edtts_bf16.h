@@ -395,6 +395,7 @@ EDTTS_DEV void attention16(QF&& qf, const __bf16* __restrict__ Kb, const __bf16*
         nm[h][ft] = 0.f;
       }
     auto step = [&](bool first, int c, int cnext2, bf8 (&KA)[HP][2], bf8 (&VA)[HP][2]) {
+      if (hd == 0) STAMPX(stamps, sidx++);
       f4 S[HP][2][NF];
       if (chunk_is_interior(c)) {
 #pragma unroll
@@ -430,6 +431,7 @@ EDTTS_DEV void attention16(QF&& qf, const __bf16* __restrict__ Kb, const __bf16*
       }
 #pragma unroll
       for (int h = 0; h < HP; ++h) load_k(hd + h, cnext2, KA[h]);  // (re-reads a valid tile past the last step)
+      if (hd == 0) STAMPX(stamps, sidx++);
       f4 P[HP][2][NF], ps[HP][NF];
       auto exp_and_sum = [&](int h, int ft, float m) {
 #pragma unroll
@@ -504,6 +506,7 @@ EDTTS_DEV void attention16(QF&& qf, const __bf16* __restrict__ Kb, const __bf16*
           lvec[h][ft] += ps[h][ft];
           pb[h][ft] = pack8(P[h][0][ft], P[h][1][ft]);
         }
+      if (hd == 0) STAMPX(stamps, sidx++);
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -512,7 +515,11 @@ EDTTS_DEV void attention16(QF&& qf, const __bf16* __restrict__ Kb, const __bf16*
           for (int h = 0; h < HP; ++h) O[h][dt][ft] = EDTTS_MFMA16(VA[h][dt], pb[h][ft], O[h][dt][ft]);
 #pragma unroll
       for (int h = 0; h < HP; ++h) load_v(hd + h, cnext2, VA[h]);
+      if (hd == 0) STAMPX(stamps, sidx++);
     };
+    // (Measured: computing the conditional step under its condition with its tile requests made unconditional -- so that hipcc's
+    // waitcnt pass counts exactly -- evens out the per-step stamps but not the call time, 39.2 vs 38.75 ms; unconditional step pairs
+    // plus a tail step, a fourth copy of the step: 53.6 ms, 202 spilled registers.)
     step(true, chunk_of(0), chunk_of(2), KA0, VA0);
     for (int st = 1; st < nchunk; st += 2) {
       step(false, chunk_of(st), chunk_of(st + 2), KA1, VA1);
@@ -712,7 +719,10 @@ EDTTS_DEV void qkv_tail16(Ring16<C>& ring, const bf8 (&hn)[C::KT][C::NF], const 
       gemm16_pair<C::KT, false>(ring, hn, acc[0], acc[1]);
       // q: row-major [frame][H] (read back by this wave only); k: tile-contiguous image [head p][key tile][16 keys][32 slots].
       // PLAIN stores, not streaming ones: on gfx9 stores retire through the same in-order vmcnt as the ring's DMAs, and a
-      // nontemporal store takes microseconds to be acknowledged -- scratch/ring_probe.cpp: 9 060 vs 1 920 cycles per phase
+      // nontemporal store takes microseconds to be acknowledged -- scratch/ring_probe.cpp: 9 060 vs 1 920 cycles per phase.
+      // (Measured and dropped: the residual tile's 32 stores spread over the q phases instead of one burst in front of the tail,
+      // with and without an allowance for the known younger stores in the ring's counted vmcnt waits -- 38.6 - 38.9 ms either way;
+      // skipping the q / k / v^T stores altogether: 36.8 ms.)
       __bf16* dst = which == 0 ? qo + rowbase * C::H + 32 * p + 8 * g
                                : ko + ((size_t)(b * C::HEADS + p) * (a.Tp >> 4) + (m0 >> 4)) * 512 + fq * 32 + 8 * g;
       const size_t fstride = which == 0 ? (size_t)16 * C::H : 512;
@@ -894,7 +904,11 @@ __global__ __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) void k_layer16(K
     auto qf = [&](int hd, int ft) { return *reinterpret_cast<const bf8*>(qrow + (size_t)ft * 16 * C::H + hd * C::DH); };
     attention16<C, true>(qf, reinterpret_cast<const __bf16*>(a.k) + (size_t)b * a.Tp * C::H,
                          reinterpret_cast<const __bf16*>(a.vT) + (size_t)b * C::H * a.Tp, a.Tp, a.T, a.window, m0, lane,
-                         [&](int, const bf8 (&ob)[NF]) { ktile16<C::HT>(ring, ob, h); });  // h += Wo[:, head] . O
+                         [&](int, const bf8 (&ob)[NF]) { ktile16<C::HT>(ring, ob, h); }  // h += Wo[:, head] . O
+#ifdef EDTTS_STAMPS
+                         , a.stamps ? a.stamps + 8 : nullptr
+#endif
+                         );
   }
   STAMP16(1);
   // ---- x = x + cross_attn(norm2(x), context)   (transformer.py:151, mla.py:118-194) ----
@@ -972,7 +986,7 @@ __global__ __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) void k_layer16(K
                           reinterpret_cast<const __bf16*>(a.vcT) + (size_t)b * C::H * a.Sp, a.Sp, a.S, -1, m0, lane,
                           [&](int, const bf8 (&ob)[NF]) { ktile16<C::HT>(ring, ob, h); }
 #ifdef EDTTS_STAMPS
-                          , a.stamps ? a.stamps + 8 : nullptr
+                          , a.stamps ? a.stamps + 40 : nullptr
 #endif
                           );
   }

@@ -27,10 +27,11 @@ for l in (1, 4):
     print(f"layer {l}: total {tot} memtime ticks (100 MHz constant clock? see below)")
     for n, v in zip(names, d): print(f"   {n:55s} {v:9d}  {100.0*v/tot:5.1f} %")
 
-# fine-grained: cross-attention head 0 of layer 4, 4 stamps per step: [start | after QK issue + K request | after softmax + pack | after PV issue + V request]
-fs = full[4, 8:8 + 4 * 16].view(16, 4)
-print("cross-attention head 0, per step: QK+loads | softmax | PV+loads | (gap to next step start)")
-for i in range(16):
-    a, b, c, d = fs[i].tolist()
-    nxt = fs[i + 1, 0].item() if i < 15 else d
-    print(f"  step {i:2d}: {b-a:6d} {c-b:6d} {d-c:6d} {nxt-d:6d}   total {nxt-a}")
+# fine-grained: first head pair of layer 4, 4 stamps per step: [start | after QK issue + K request | after softmax + pack | after PV issue + V request]
+for name, off, n in (("self-attention", 8, 5), ("cross-attention", 40, 16)):
+    fs = full[4, off:off + 4 * n].view(n, 4)
+    print(f"{name}, heads 0+1, per step: QK+loads | softmax | PV+loads | (gap to next step start)")
+    for i in range(n):
+        a, b, c, d = fs[i].tolist()
+        nxt = fs[i + 1, 0].item() if i < n - 1 else d
+        print(f"  step {i:2d}: {b-a:6d} {c-b:6d} {d-c:6d} {nxt-d:6d}   total {nxt-a}")
