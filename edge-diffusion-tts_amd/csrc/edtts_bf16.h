@@ -30,8 +30,14 @@ typedef float f2v __attribute__((ext_vector_type(2)));
 #define EDTTS_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
 
 #ifdef EDTTS_STAMPS
-#define STAMP16(i) do { if (a.stamps && blockIdx.x == 0 && threadIdx.x == 0) a.stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
-#define STAMPX(p, i) do { if ((p) && blockIdx.x == 0 && threadIdx.x == 0) (p)[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#ifndef EDTTS_STAMP_HEAD
+#define EDTTS_STAMP_HEAD 0     // head (pair) whose attention steps carry the fine-grained stamps
+#endif
+#ifndef EDTTS_STAMP_THREAD
+#define EDTTS_STAMP_THREAD 0   // first lane of the stamped wave of block 0 (192: wave 3 = frames 96..127, an interior tile)
+#endif
+#define STAMP16(i) do { if (a.stamps && blockIdx.x == 0 && threadIdx.x == EDTTS_STAMP_THREAD) a.stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#define STAMPX(p, i) do { if ((p) && blockIdx.x == 0 && threadIdx.x == EDTTS_STAMP_THREAD) (p)[i] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define STAMP16(i) do { } while (0)
 #define STAMPX(p, i) do { } while (0)
@@ -395,7 +401,7 @@ EDTTS_DEV void attention16(QF&& qf, const __bf16* __restrict__ Kb, const __bf16*
         nm[h][ft] = 0.f;
       }
     auto step = [&](bool first, int c, int cnext2, bf8 (&KA)[HP][2], bf8 (&VA)[HP][2]) {
-      if (hd == 0) STAMPX(stamps, sidx++);
+      if (hd == EDTTS_STAMP_HEAD) STAMPX(stamps, sidx++);
       f4 S[HP][2][NF];
       if (chunk_is_interior(c)) {
 #pragma unroll
@@ -431,7 +437,7 @@ EDTTS_DEV void attention16(QF&& qf, const __bf16* __restrict__ Kb, const __bf16*
       }
 #pragma unroll
       for (int h = 0; h < HP; ++h) load_k(hd + h, cnext2, KA[h]);  // (re-reads a valid tile past the last step)
-      if (hd == 0) STAMPX(stamps, sidx++);
+      if (hd == EDTTS_STAMP_HEAD) STAMPX(stamps, sidx++);
       f4 P[HP][2][NF], ps[HP][NF];
       auto exp_and_sum = [&](int h, int ft, float m) {
 #pragma unroll
@@ -506,7 +512,7 @@ EDTTS_DEV void attention16(QF&& qf, const __bf16* __restrict__ Kb, const __bf16*
           lvec[h][ft] += ps[h][ft];
           pb[h][ft] = pack8(P[h][0][ft], P[h][1][ft]);
         }
-      if (hd == 0) STAMPX(stamps, sidx++);
+      if (hd == EDTTS_STAMP_HEAD) STAMPX(stamps, sidx++);
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -515,7 +521,7 @@ EDTTS_DEV void attention16(QF&& qf, const __bf16* __restrict__ Kb, const __bf16*
           for (int h = 0; h < HP; ++h) O[h][dt][ft] = EDTTS_MFMA16(VA[h][dt], pb[h][ft], O[h][dt][ft]);
 #pragma unroll
       for (int h = 0; h < HP; ++h) load_v(hd + h, cnext2, VA[h]);
-      if (hd == 0) STAMPX(stamps, sidx++);
+      if (hd == EDTTS_STAMP_HEAD) STAMPX(stamps, sidx++);
     };
     // (Measured: computing the conditional step under its condition with its tile requests made unconditional -- so that hipcc's
     // waitcnt pass counts exactly -- evens out the per-step stamps but not the call time, 39.2 vs 38.75 ms; unconditional step pairs
@@ -572,7 +578,7 @@ EDTTS_DEV void attention16(QF&& qf, const __bf16* __restrict__ Kb, const __bf16*
       nm[ft] = 0.f;
     }
     auto step = [&](bool first, int c, int cnext2, bf8 (&KA)[2], bf8 (&VA)[2]) {
-      if (hd == 0) STAMPX(stamps, sidx++);
+      if (hd == EDTTS_STAMP_HEAD) STAMPX(stamps, sidx++);
       f4 S[2][NF];
       if (chunk_is_interior(c)) {
         // the reference tile rides in as the C operand itself (written as S = NM; S = mfma(.., S) it cost 16 accumulator moves
@@ -589,7 +595,7 @@ EDTTS_DEV void attention16(QF&& qf, const __bf16* __restrict__ Kb, const __bf16*
           for (int ft = 0; ft < NF; ++ft) S[t][ft] = EDTTS_MFMA16(KA[t], q[ft], S[t][ft]);
       }
       load_k(hd, cnext2, KA);  // (re-reads a valid tile past the last step)
-      if (hd == 0) STAMPX(stamps, sidx++);
+      if (hd == EDTTS_STAMP_HEAD) STAMPX(stamps, sidx++);
       f4 P[2][NF], ps[NF];
       auto lane_max = [&](int ft) {
         f4 mv = S[0][ft];
@@ -658,13 +664,13 @@ EDTTS_DEV void attention16(QF&& qf, const __bf16* __restrict__ Kb, const __bf16*
         lvec[ft] += ps[ft];
         pb[ft] = pack8(P[0][ft], P[1][ft]);
       }
-      if (hd == 0) STAMPX(stamps, sidx++);
+      if (hd == EDTTS_STAMP_HEAD) STAMPX(stamps, sidx++);
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
         for (int ft = 0; ft < NF; ++ft) O[dt][ft] = EDTTS_MFMA16(VA[dt], pb[ft], O[dt][ft]);
       load_v(hd, cnext2, VA);
-      if (hd == 0) STAMPX(stamps, sidx++);
+      if (hd == EDTTS_STAMP_HEAD) STAMPX(stamps, sidx++);
     };
     // (Measured alternatives, same device: groups of KD unconditional steps + a load-free tail so that hipcc's waitcnt pass sees
     // the same number of outstanding loads on every path -- KD=2: 50.1 ms, KD=4: 46.2 ms against 45.7 ms for this loop; fully
