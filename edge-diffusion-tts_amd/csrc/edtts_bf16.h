@@ -29,10 +29,10 @@ typedef float f2v __attribute__((ext_vector_type(2)));
 
 #define EDTTS_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
 
-#ifdef EDTTS_STAMPS
 #ifndef EDTTS_STAMP_HEAD
-#define EDTTS_STAMP_HEAD 0     // head (pair) whose attention steps carry the fine-grained stamps
+#define EDTTS_STAMP_HEAD 0     // head (pair) whose attention steps carry the fine-grained stamps (EDTTS_STAMPS builds)
 #endif
+#ifdef EDTTS_STAMPS
 #ifndef EDTTS_STAMP_THREAD
 #define EDTTS_STAMP_THREAD 0   // first lane of the stamped wave of block 0 (192: wave 3 = frames 96..127, an interior tile)
 #endif
