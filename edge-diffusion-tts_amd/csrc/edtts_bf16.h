@@ -716,8 +716,10 @@ EDTTS_DEV void qkv_tail16(Ring16<C>& ring, const bf8 (&hn)[C::KT][C::NF], const 
   __bf16* const qo = reinterpret_cast<__bf16*>(a.q_out);
   __bf16* const ko = reinterpret_cast<__bf16*>(a.k_out);
   __bf16* const vo = reinterpret_cast<__bf16*>(a.vT_out);
+  STAMP16(120);
 #pragma unroll
   for (int which = 0; which < 2; ++which) {
+    STAMP16(121 + which);  // (121: start of the q phases, 122: start of the k phases)
     for (int p = 0; p < C::KT; ++p) {
       f4 acc[2][NF];
 #pragma unroll
@@ -738,6 +740,7 @@ EDTTS_DEV void qkv_tail16(Ring16<C>& ring, const bf8 (&hn)[C::KT][C::NF], const 
         *reinterpret_cast<f4*>(dst + ft * fstride) = as_f4(pack8(acc[0][ft], acc[1][ft]));
     }
   }
+  STAMP16(123);  // start of the v^T phases
   for (int p = 0; p < C::KT; ++p) {
     f4 acc[2][NF];
 #pragma unroll

@@ -27,6 +27,8 @@ for l in (1, 4):
     print(f"layer {l}: total {tot} memtime ticks (100 MHz constant clock? see below)")
     for n, v in zip(names, d): print(f"   {n:55s} {v:9d}  {100.0*v/tot:5.1f} %")
 
+t = full[4, 120:124].tolist() + [int(st[4, 5])]
+print(f"layer 4 tail: entry->q {t[1]-int(st[4,4])} (store h, norm) | q phases {t[2]-t[1]} | k phases {t[3]-t[2]} | v^T phases {t[4]-t[3]}")
 # fine-grained: first head pair of layer 4, 4 stamps per step: [start | after QK issue + K request | after softmax + pack | after PV issue + V request]
 for name, off, n in (("self-attention", 8, 5), ("cross-attention", 40, 16)):
     fs = full[4, off:off + 4 * n].view(n, 4)
