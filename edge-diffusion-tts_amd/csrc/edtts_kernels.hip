@@ -105,8 +105,11 @@ struct Layout {
   size_t tok, semp, semp_b, t1T, t1b, t3T, t3b, step, inp, inp_b, pe, cpe, fnw, fnb, outp_b, freqs;
   LayerLayout layer[kMaxLayers];
   size_t s_outp;  // stream: final out_proj [MT n-tiles][HT]
+  size_t s_ctx16; // bf16 instance: fragment stream of the context kernel, per layer kv_down (n-tile pairs) | kv_up (n-tile pairs)
   size_t total;
 };
+// fragments of one layer in the bf16 context stream: kv_down R x H (RT n-tiles x H/32 k-tiles) + kv_up 2H x R
+static size_t ctx16_frags(const Layout& lo) { return (size_t)lo.RT * (lo.H / 32) + (size_t)2 * lo.HT * (lo.R / 32); }
 constexpr size_t kFrag = 256;  // floats per fragment (64 lanes x float4)
 
 static size_t align64(size_t v) { return (v + 63) & ~(size_t)63; }
@@ -149,6 +152,7 @@ static int make_layout(const EdttsDims* d, Layout* lo) {
   if (lo->BF16) {
     // bf16 fragments: 16 outputs x 32 inputs = 1 KiB (= kFrag floats), see edtts_bf16.h
     const size_t KT = H / 32, MKT = (lo->MEL + 31) / 32, MTP = (MT + 1) / 2;
+    lo->s_ctx16 = o; o += (size_t)lo->L * ctx16_frags(*lo) * kFrag;  // (the decoder's stream follows: ring read-ahead stays inside the blob)
     lo->inp = o; o += MKT * HT * kFrag;  // in_proj, k-major
     for (int l = 0; l < lo->L; ++l) {
       LayerLayout& y = lo->layer[l];
@@ -855,6 +859,7 @@ struct CtxArgs {
   unsigned kvd[kMaxLayers], kvn[kMaxLayers], kvu[kMaxLayers];
   float *kc, *vcT;  // [L][B][Sp][H], [L][B][VR][Sp]
   unsigned* err;    // index-error word of the workspace
+  const float* stream16;  // k_ctx16: bf16 fragment stream (Layout::s_ctx16)
 };
 // BF16OUT: the cache is written in the bf16 images of edtts_bf16.h (K rows with each head's 32 features in slot order, V^T with
 // each chunk's 32 tokens in slot order); the arithmetic stays fp32 either way (once per call).
@@ -985,6 +990,154 @@ __global__ __launch_bounds__(64 * kCtxWaves) void k_ctx(CtxArgs a) {
     }
   }
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// bf16 context kernel: the same embedding / positional / kv_down -> RMSNorm -> kv_up chain (mla.py:144-153) with both
+// projections on v_mfma_f32_16x16x32_bf16 (fp32 accumulate, fp32 norm), weights through the block-shared LDS ring of
+// edtts_bf16.h.  A wave owns 32 context tokens; per layer 12 phases at H = 256: 4 of kv_down (an n-tile pair over all k-tiles
+// each), 8 of kv_up (two n-tile pairs = two heads each; K heads first, then V heads).  K comes out of the usual product
+// (C/D = [feature][token] -> one 16-byte K-image store per lane and token tile), V^T out of the SWAPPED product (activations as A:
+// C/D = [token][feature] -> one 16-byte V^T-image store per lane and d-tile), as in qkv_tail16.
+// ---------------------------------------------------------------------------------------------------------
+template <class C>
+__global__ __launch_bounds__(C::THREADS, 1) void k_ctx16(CtxArgs a) {
+  using namespace edtts16;
+  extern __shared__ __attribute__((aligned(16))) f4 ring_lds_ctx16[];
+  constexpr int RT = C::R / 16, RK = C::R / 32, KT = C::KT;
+  static_assert(C::NF == 2 && C::R % 32 == 0 && 2 * KT == C::PH && C::PH % (2 * RK) == 0, "context kernel geometry");
+  constexpr int PPP = C::PH / (2 * RK);  // kv_up n-tile pairs (= heads) per phase
+  static_assert(C::HEADS % PPP == 0, "K heads and V heads do not share a phase");
+  const TileId tl = wave_tile(a.B, a.Sp, C::WAVES, 32);
+  const bool valid = tl.valid;  // (a padding wave works on a copy of the last tile -- ring barriers and DMAs -- and stores nothing)
+  const int lane = threadIdx.x & 63, fq = lane & 15, g = lane >> 4;
+  const int b = tl.b, m0 = tl.m0;
+  LdsRing<C> ring;
+  ring.start(a.stream16, ring_lds_ctx16, __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane);
+  f4 ctx[C::HT][2];
+  if (a.sem_feat != nullptr) {
+    // context = sem_proj(sem_features)   (decoder.py:83-85): once per call, fp32 fragments as in k_ctx
+    const int SKT = a.SD / 16;
+    const f4* wp = reinterpret_cast<const f4*>(a.semp) + lane;
+#pragma unroll
+    for (int nt = 0; nt < C::HT; ++nt) ctx[nt][0] = ctx[nt][1] = ldg4(a.semp_b + 16 * nt + 4 * g);
+    for (int kt = 0; kt < SKT; ++kt) {
+      f4 xin[2];
+#pragma unroll
+      for (int ft = 0; ft < 2; ++ft) {
+        const int s = m0 + 16 * ft + fq;
+        xin[ft] = s < a.S ? ldg4(a.sem_feat + ((size_t)b * a.S + s) * a.SD + 16 * kt + 4 * g) : splat(0.f);
+      }
+#pragma unroll
+      for (int nt = 0; nt < C::HT; ++nt) {
+        const f4 w = wp[(nt * SKT + kt) * 64];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          ctx[nt][0] = EDTTS_MFMA(w[r], xin[0][r], ctx[nt][0]);
+          ctx[nt][1] = EDTTS_MFMA(w[r], xin[1][r], ctx[nt][1]);
+        }
+      }
+    }
+  } else {
+#pragma unroll
+    for (int ft = 0; ft < 2; ++ft) {
+      const int s = m0 + 16 * ft + fq;
+      long tk = s < a.S ? (long)a.sem_idx[(size_t)b * a.S + s] : 0;
+      if (tk < 0 || tk >= a.n_tok) {  // nn.Embedding would raise IndexError: clamp (never fault) and leave a mark for the host
+        atomicOr(a.err, (unsigned)EDTTS_IDX_SEM);
+        tk = tk < 0 ? 0 : a.n_tok - 1;
+      }
+      const float* row = a.tok + (size_t)tk * C::H + 4 * g;
+#pragma unroll
+      for (int nt = 0; nt < C::HT; ++nt) ctx[nt][ft] = ldg4(row + 16 * nt);  // decoder.py:88
+    }
+  }
+#pragma unroll
+  for (int ft = 0; ft < 2; ++ft) {
+    int s = m0 + 16 * ft + fq;
+    s = s < a.max_cpos ? s : a.max_cpos - 1;
+    const float* row = a.cpe + (size_t)s * C::H + 4 * g;
+#pragma unroll
+    for (int nt = 0; nt < C::HT; ++nt) ctx[nt][ft] += ldg4(row + 16 * nt);  // decoder.py:93
+  }
+  bf8 xin[KT][2];  // the context tile as the B operand of kv_down (the same for every layer)
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+    for (int ft = 0; ft < 2; ++ft) xin[kt][ft] = pack8(ctx[2 * kt][ft], ctx[2 * kt + 1][ft]);
+  const size_t hstride = (size_t)32 * a.Sp;
+  for (int l = 0; l < a.L; ++l) {
+    // c = RMSNorm_R(kv_down(ctx))   (mla.py:144-145)
+    f4 c[RT][2];
+#pragma unroll
+    for (int p = 0; p < RT / 2; ++p) {
+      c[2 * p][0] = c[2 * p][1] = c[2 * p + 1][0] = c[2 * p + 1][1] = splat(0.f);
+      gemm16_pair<KT, false>(ring, xin, c[2 * p], c[2 * p + 1]);
+    }
+    bf8 cn[RK][2];
+    {
+      float rs[2];
+#pragma unroll
+      for (int ft = 0; ft < 2; ++ft) {
+        float ss = 0.f;
+#pragma unroll
+        for (int t = 0; t < RT; ++t) ss += hsum(c[t][ft] * c[t][ft]);
+        rs[ft] = rsqrtf(group_sum(ss) * (1.0f / C::R) + 1e-6f);
+      }
+      const float* w = a.blob + a.kvn[l];
+#pragma unroll
+      for (int kt = 0; kt < RK; ++kt) {
+        const f4 w0 = ldg4(w + 32 * kt + 4 * g), w1 = ldg4(w + 32 * kt + 16 + 4 * g);
+#pragma unroll
+        for (int ft = 0; ft < 2; ++ft) cn[kt][ft] = pack8(c[2 * kt][ft] * rs[ft] * w0, c[2 * kt + 1][ft] * rs[ft] * w1);
+      }
+    }
+    // kv = kv_up(c): first H outputs = K, second H = V   (mla.py:150-153)
+    __bf16* const kimg = reinterpret_cast<__bf16*>(a.kc) + ((size_t)l * a.B + b) * a.Sp * C::H;
+    __bf16* const vimg = reinterpret_cast<__bf16*>(a.vcT) + ((size_t)l * a.B + b) * a.Sp * C::H;
+    for (int ph = 0; ph < 2 * C::HEADS / PPP; ++ph) {
+      const f4* fr = ring.acquire();
+      f4 fg[C::PH];
+#pragma unroll
+      for (int i = 0; i < C::PH; ++i) fg[i] = fr[i * 64];
+      __builtin_amdgcn_sched_barrier(0);
+      const bool isv = ph >= C::HEADS / PPP;  // (wave-uniform)
+#pragma unroll
+      for (int pp = 0; pp < PPP; ++pp) {
+        const int head = (isv ? ph - C::HEADS / PPP : ph) * PPP + pp;
+        f4 acc[2][2] = {{splat(0.f), splat(0.f)}, {splat(0.f), splat(0.f)}};
+        if (!isv) {
+#pragma unroll
+          for (int kt = 0; kt < RK; ++kt)
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+              for (int ft = 0; ft < 2; ++ft)
+                acc[u][ft] = EDTTS_MFMA16(as_bf8(fg[pp * 2 * RK + 2 * kt + u]), cn[kt][ft], acc[u][ft]);
+          // K image [head][token tile][16 tokens][32 slots]
+          __bf16* d = kimg + head * hstride + (size_t)(m0 >> 4) * 512 + fq * 32 + 8 * g;
+          if (valid)
+#pragma unroll
+            for (int ft = 0; ft < 2; ++ft) *reinterpret_cast<f4*>(d + ft * 512) = as_f4(pack8(acc[0][ft], acc[1][ft]));
+        } else {
+#pragma unroll
+          for (int kt = 0; kt < RK; ++kt)
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+              for (int ft = 0; ft < 2; ++ft)
+                acc[u][ft] = EDTTS_MFMA16(cn[kt][ft], as_bf8(fg[pp * 2 * RK + 2 * kt + u]), acc[u][ft]);  // C/D = [token 4g+r of tile ft][feature 16u + fq]
+          // V^T image [head][32-token chunk][d-tile u][16 d][32 token slots]; token 16 t + 4 g + r of the chunk sits at slot 8 g + 4 t + r
+          __bf16* d = vimg + head * hstride + (size_t)(m0 >> 5) * 1024 + fq * 32 + 8 * g;
+          if (valid)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) *reinterpret_cast<f4*>(d + u * 512) = as_f4(pack8(acc[u][0], acc[u][1]));
+        }
+      }
+    }
+  }
+  ring.drain();
+}
+
 
 // =========================================================================================================
 // standalone DDIM / DDPM updates (HBM-bound: read x, eps ; write x_prev, x0 = 16 B/element)
@@ -1438,6 +1591,7 @@ struct Launcher16 {
     if (done[dev]) return EDTTS_OK;
     const int lds = C::LDS_BYTES;
     HIP_TRY(hipFuncSetAttribute((const void*)edtts16::k_prologue16<C>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    HIP_TRY(hipFuncSetAttribute((const void*)k_ctx16<C>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     HIP_TRY(hipFuncSetAttribute((const void*)edtts16::k_layer16<C, TAIL_QKV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     HIP_TRY(hipFuncSetAttribute((const void*)edtts16::k_layer16<C, TAIL_EPS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     HIP_TRY(hipFuncSetAttribute((const void*)edtts16::k_layer16<C, TAIL_DDIM>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -1472,8 +1626,17 @@ struct Launcher16 {
     }
     a.kc = wsb + ws.kc; a.vcT = wsb + ws.vcT;
     a.err = reinterpret_cast<unsigned*>(wsb + ws.err);
-    hipLaunchKernelGGL((k_ctx<C2, true>), dim3((B * (ws.Sp / 32) + kCtxWaves - 1) / kCtxWaves), dim3(64 * kCtxWaves), 0, st, a);
-    LAUNCH_CHECK("k_ctx<bf16 out>");
+#ifndef EDTTS16_CTX_F32
+#define EDTTS16_CTX_F32 0   // 1: the context cache from the fp32-arithmetic kernel (k_ctx<.., bf16 out>), as before
+#endif
+    if (EDTTS16_CTX_F32) {
+      hipLaunchKernelGGL((k_ctx<C2, true>), dim3((B * (ws.Sp / 32) + kCtxWaves - 1) / kCtxWaves), dim3(64 * kCtxWaves), 0, st, a);
+      LAUNCH_CHECK("k_ctx<bf16 out>");
+    } else {
+      a.stream16 = blob + lo.s_ctx16;
+      hipLaunchKernelGGL((k_ctx16<C>), dim3((B * (ws.Sp / 32) + C::WAVES - 1) / C::WAVES), dim3(C::THREADS), C::LDS_BYTES, st, a);
+      LAUNCH_CHECK("k_ctx16");
+    }
     return EDTTS_OK;
   }
   static int forward(const Layout& lo, const float* blob, const Workspace& ws, float* wsb, int B, int T, int S, int window,
@@ -1722,6 +1885,9 @@ int edtts_pack_weights(const EdttsDims* dims, const void* const* slots, int n_sl
     // the query rows carry the softmax scale: scores come out of K Q^T in the exp2 domain, log2(e) / sqrt(head_dim)
     const float qscale = 1.4426950408889634f / sqrtf((float)DH);
     if (lo.BF16) {
+      float* c16 = blob + lo.s_ctx16 + (size_t)l * ctx16_frags(lo) * kFrag;
+      TRY(pack_gemm16(st, W(L_KVD_W), H, R, H, RT, KT16, 0, c16));                                   // kv_down as n-tile pairs
+      TRY(pack_gemm16(st, W(L_KVU_W), R, 2 * H, R, 2 * HT, R / 32, 0, c16 + (size_t)RT * KT16 * kFrag));  // kv_up: K heads | V heads
       TRY(pack_gemm16(st, W(L_QKV_W), H, 3 * H, H, 3 * HT, KT16, 0, blob + y.s_qkv, 0, 0, H, qscale));  // q | k | v as n-tile pairs
       float* s16 = blob + y.s_body;
       TRY(pack_gemm16(st, W(L_PROJ_W), H, H, H, HT, KT16, 1, s16));                       // k-major: k-tile = head
