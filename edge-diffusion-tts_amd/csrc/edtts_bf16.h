@@ -458,18 +458,22 @@ EDTTS_DEV void attention16(QF&& qf, const __bf16* __restrict__ Kb, const __bf16*
             const float m = gm > -1e30f ? gm : 0.f;
             nm[h][ft] = -m;
             NM[h][ft] = splat(-m);
+            asm volatile("" : "+a"(NM[h][ft]));  // the -m tile lives in AGPRs: it is an accumulator input and nothing else (else 16 v_accvgpr_write per step)
             exp_and_sum(h, ft, m);
           }
       } else {
         const float lim = 4294967296.f;  // 2^32 (kDefer)
-        bool over = false;
+        // one test for the whole step: all probabilities are >= 0, so the sum over both heads and query tiles exceeds the limit
+        // (or is not finite) whenever one row's does -- a false positive only moves reference points early
+        f4 tot = splat(0.f);
 #pragma unroll
         for (int h = 0; h < HP; ++h)
 #pragma unroll
           for (int ft = 0; ft < NF; ++ft) {
             exp_and_sum(h, ft, 0.f);
-            over = over || !(hsum(ps[h][ft]) <= lim);
+            tot += ps[h][ft];
           }
+        const bool over = !(hsum(tot) <= lim);
         if (__any(over)) {
           // rare path (inputs through a volatile asm: see the single-head step)
           f4 T[HP][2][NF];
@@ -493,6 +497,7 @@ EDTTS_DEV void attention16(QF&& qf, const __bf16* __restrict__ Kb, const __bf16*
               const float alpha = fast_exp2(-dl);
               nm[h][ft] -= dl;
               NM[h][ft] = splat(nm[h][ft]);
+              asm volatile("" : "+a"(NM[h][ft]));
               lvec[h][ft] *= alpha;
               O[h][0][ft] *= alpha;
               O[h][1][ft] *= alpha;
