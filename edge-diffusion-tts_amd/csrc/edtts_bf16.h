@@ -158,6 +158,14 @@ struct LdsRing {
 };
 template <class C> using Ring16 = LdsRing<C>;
 
+// Fragment i of an acquired phase.  The slot base goes through an opaque register so that hipcc addresses the N reads of a phase
+// as ONE base + immediate offsets (ds_read_b128 ... offset:1024 i) instead of materialising N addresses with N v_add_u32.
+typedef __attribute__((address_space(3))) const f4* lds_cf4_t;
+EDTTS_DEV lds_cf4_t phase_base(const f4* fr) {
+  lds_cf4_t p = (lds_cf4_t)fr;
+  asm volatile("" : "+v"(p));
+  return p;
+}
 // two n-tiles at once from a phase that interleaves their fragments per k-tile ([kt][tile a | tile b]).
 // SWAP: activations as the A operand, weights as B -> C/D = [frame][feature] (used for v^T).
 template <int KT, bool SWAP, class C>
@@ -169,8 +177,9 @@ EDTTS_DEV void gemm16_pair(LdsRing<C>& ring, const bf8 (&in)[KT][C::NF], f4 (&a)
   // phase's fragments right after this phase's MFMAs -- to take the barrier and the LDS round trip off the critical path -- was
   // measured 18 % slower: the 64 registers held across the phase boundary bring the spills back.)
   f4 fg[2 * KT];
+  const lds_cf4_t fb0 = phase_base(fr);
 #pragma unroll
-  for (int i = 0; i < 2 * KT; ++i) fg[i] = fr[i * 64];
+  for (int i = 0; i < 2 * KT; ++i) fg[i] = fb0[i * 64];
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int kt = 0; kt < KT; ++kt) {
@@ -188,8 +197,9 @@ EDTTS_DEV void ktile16(LdsRing<C>& ring, const bf8 (&in)[C::NF], f4 (&acc)[NT][C
   static_assert(NT == C::PH, "one k-tile over all n-tiles is one phase");
   const f4* fr = ring.acquire();
   f4 fg[NT];
+  const lds_cf4_t fb0 = phase_base(fr);
 #pragma unroll
-  for (int i = 0; i < NT; ++i) fg[i] = fr[i * 64];
+  for (int i = 0; i < NT; ++i) fg[i] = fb0[i * 64];
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {

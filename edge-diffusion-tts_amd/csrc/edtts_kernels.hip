@@ -1095,7 +1095,7 @@ __global__ __launch_bounds__(C::THREADS, 1) void k_ctx16(CtxArgs a) {
     __bf16* const kimg = reinterpret_cast<__bf16*>(a.kc) + ((size_t)l * a.B + b) * a.Sp * C::H;
     __bf16* const vimg = reinterpret_cast<__bf16*>(a.vcT) + ((size_t)l * a.B + b) * a.Sp * C::H;
     for (int ph = 0; ph < 2 * C::HEADS / PPP; ++ph) {
-      const f4* fr = ring.acquire();
+      const lds_cf4_t fr = phase_base(ring.acquire());
       f4 fg[C::PH];
 #pragma unroll
       for (int i = 0; i < C::PH; ++i) fg[i] = fr[i * 64];
