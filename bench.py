@@ -115,6 +115,41 @@ def pmc_traffic(args):
     return {"bytes": rd + wr, "read": rd, "write": wr}, "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of `bench.py --steps 2 --warmup 1`, mean over k_layer launches; FETCH_SIZE x2 (gfx950 16 B/lane correction)"
 
 
+# ------------------------------------------------------------------------------------------------ self-launch
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without an outer torchrun: start N copies of this script, one per GPU (RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* set as torch.distributed.run would), relay rank 0's JSON line, exit with the worst child status.
+    The parent never imports torch or touches a GPU (a process that has initialised the GPU must not exec or fork workers);
+    a rank that dies takes the others down instead of leaving them waiting in a collective."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    base = dict(os.environ, WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), EDTTS_BENCH_SPAWNED="1")
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (RCCL across processes needs it on this driver)
+    import __graft_entry__
+    __graft_entry__.build()  # once, before any rank starts (hipcc only; no GPU call)
+    procs = []
+    for r in range(n):
+        env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    live = list(procs)
+    while live:
+        time.sleep(0.2)
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+                for q in live:  # exact PIDs we started
+                    q.terminate()
+    return rc
+
+
 # ------------------------------------------------------------------------------------------------ main
 def main():
     ap = argparse.ArgumentParser()
@@ -138,21 +173,24 @@ def main():
     steps = args.steps if args.steps is not None else C["steps"]
     warmup = args.warmup if args.warmup is not None else max(2, min(10, steps // 10))
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args.gpus))  # plain `python bench.py --gpus N`: this process only launches and relays
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`")
         raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
     extras = world == 1 and not args.pmc_child
+    # EDTTS_BENCH_STUB=1 (tests only): no GPU -- a stand-in sampler on the CPU and gloo, to exercise the launcher, the sharding,
+    # the collective and the JSON contract of the multi-rank path where no GPU exists.  Its numbers mean nothing.
+    stub = os.environ.get("EDTTS_BENCH_STUB", "0") == "1"
 
     # ---- everything that must precede the first GPU call: build, PMC child runs -------------------------------------------
     import __graft_entry__
-    if rank == 0:
+    if rank == 0 and os.environ.get("EDTTS_BENCH_SPAWNED") != "1":
         __graft_entry__.build()  # (re)builds only when stale; the driver has run build() already
     traffic, traffic_src = None, "skipped"
-    if extras and not args.no_pmc and not args.no_roofline:
+    if extras and not stub and not args.no_pmc and not args.no_roofline:
         traffic, traffic_src = pmc_traffic(args)
 
     import torch
@@ -162,34 +200,54 @@ def main():
     rehearsal = os.environ.get("EDTTS_BENCH_REHEARSAL", "0") == "1"
     if rehearsal:
         local_rank = 0
+    rccl_ranks = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        if rehearsal:
+        if stub:
             dist.init_process_group("gloo")
         else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            torch.cuda.set_device(local_rank)
+            if rehearsal:
+                dist.init_process_group("gloo")
+            else:
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         dist.barrier()  # rank 0 has finished building
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
-    torch.cuda.set_device(dev)
+        # how many ranks the collective backend really joined: an all-reduce of ones over the group the gather will use
+        one = torch.ones(1, dtype=torch.int64, device="cpu" if (stub or rehearsal) else torch.device("cuda", local_rank))
+        dist.all_reduce(one)
+        rccl_ranks = int(one.item())
+        if rccl_ranks != world:
+            raise SystemExit(f"collective backend joined {rccl_ranks} ranks, expected {world}")
+    dev = torch.device("cpu") if stub else torch.device("cuda", local_rank if world > 1 else 0)
+    if not stub:
+        torch.cuda.set_device(dev)
+
+    def sync():
+        if not stub:
+            torch.cuda.synchronize(dev)
 
     from edge_diffusion_tts_amd import CFG, DiffusionSchedule, EdgeDiffusionDecoder, EdgeInference, native, synth_state_dict
     from edge_diffusion_tts_amd.parallel import gather_batch, generate_overlapped
 
-    cfg = CFG(device="cuda", hidden=C["hidden"], layers=C["layers"], heads=C["heads"])
+    cfg = CFG(device="cpu" if stub else "cuda", hidden=C["hidden"], layers=C["layers"], heads=C["heads"])
     max_len = max(1000, T)
-    dec = EdgeDiffusionDecoder(cfg, max_len=max_len, **({"compute_dtype": args.dtype} if args.dtype != "f32" else {}))
-    sd = synth_state_dict(cfg, 0, max_pos=max_len)
-    dec.load_state_dict(sd)
-    dec = dec.to(dev).eval()
-    sch = DiffusionSchedule(cfg.diff_steps).to(dev)
-    infer = EdgeInference(cfg, sch, torch.nn.Identity(), dec)
-
     gen = torch.Generator().manual_seed(2 + rank)
     sem = torch.randint(0, cfg.codebook_size, (B, S), generator=gen).to(dev)
     micro = int(os.environ.get("EDTTS_BENCH_MICRO", "1"))  # >1 (opt-in): overlap each slice's all-gather with the next slice's compute
     gather_out = [None]
     counter = [0]
+    gather_ms = []  # filled by the separate gather-timing loop below, never inside the headline loop
+    if stub:
+        sd = infer = None
+        if C["sampler"] != "ddim":
+            raise SystemExit("EDTTS_BENCH_STUB covers the DDIM configurations only")
+    else:
+        dec = EdgeDiffusionDecoder(cfg, max_len=max_len, **({"compute_dtype": args.dtype} if args.dtype != "f32" else {}))
+        sd = synth_state_dict(cfg, 0, max_pos=max_len)
+        dec.load_state_dict(sd)
+        dec = dec.to(dev).eval()
+        sch = DiffusionSchedule(cfg.diff_steps).to(dev)
+        infer = EdgeInference(cfg, sch, torch.nn.Identity(), dec)
 
     if C["sampler"] == "ddpm":
         # BASELINE config 5: the whole 1000-step ancestral sampler captured ONCE as a hipGraph; a step = one replay.  The start
@@ -208,6 +266,9 @@ def main():
             return out_static
     else:
         def local(sem_, n_, seed_, off_):
+            if stub:  # stand-in sampler: rows that depend only on (seed, global utterance index), like the library's Philox noise
+                rows = [torch.randn(T, cfg.n_mels, generator=torch.Generator().manual_seed(seed_ * 100003 + off_ + i)) for i in range(sem_.shape[0])]
+                return torch.stack(rows).clamp_(-3, 3)
             return infer.generate_mel(sem_, n_, seed=seed_, batch_offset=off_)
 
         def step():
@@ -225,23 +286,30 @@ def main():
 
     for _ in range(warmup):
         step()
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
-    torch.cuda.synchronize(dev)
+    class _HostEvent:  # stub mode: no device, so per-step times come from the host clock
+        def record(self):
+            self.t = time.perf_counter()
+
+        def elapsed_time(self, other):
+            return (other.t - self.t) * 1e3
+
+    ev = [_HostEvent() if stub else torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    sync()
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize(dev)
+    sync()
     t0 = time.perf_counter()
     ev[0].record()
     for i in range(steps):
         out = step()
         ev[i + 1].record()
-    torch.cuda.synchronize(dev)
+    sync()
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize(dev)
+    sync()
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], device="cpu" if rehearsal else dev, dtype=torch.float64)
+        tt = torch.tensor([dt], device="cpu" if (rehearsal or stub) else dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     assert out.shape == (world * B, T, cfg.n_mels) and bool(torch.isfinite(out[:2]).all())
@@ -249,6 +317,22 @@ def main():
         return
     per_step = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(steps))
     median_ms = per_step[len(per_step) // 2]
+    if world > 1 and C["sampler"] == "ddim":
+        # the all-gather alone, in its own loop (the headline loop above carries no instrumentation): device time of
+        # gather_batch on an already computed shard, max over ranks
+        mel = local(sem, C["num_steps"], 7, rank * B)
+        for _ in range(5):
+            sync()
+            dist.barrier()
+            g0, g1 = (_HostEvent(), _HostEvent()) if stub else (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            g0.record()
+            gather_out[0] = gather_batch(mel, world * B, out=gather_out[0])
+            g1.record()
+            sync()
+            gather_ms.append(g0.elapsed_time(g1))
+        gt = torch.tensor([sorted(gather_ms)[len(gather_ms) // 2]], device="cpu" if (rehearsal or stub) else dev, dtype=torch.float64)
+        dist.all_reduce(gt, op=dist.ReduceOp.MAX)
+        gather_ms = float(gt.item())
 
     ms_per_step = dt / steps * 1e3
     frames_per_s = world * B * T / (dt / steps)
@@ -268,14 +352,23 @@ def main():
         "mels_per_s": world * B / (dt / steps),
         "timed_region_s": dt,
     }
+    if world > 1:
+        result["rccl_ranks"] = rccl_ranks  # ranks that answered an all-reduce of ones on the collective backend
+        result["collective_backend"] = dist.get_backend()
+        if C["sampler"] == "ddim":
+            result["allgather_ms"] = gather_ms  # median over 5, max over ranks, of the one all-gather per step (own loop)
+            result["allgather_bytes"] = world * B * T * cfg.n_mels * 4
     if rehearsal:
         result["note"] = "REHEARSAL: ranks share one GPU, gloo collective -- not a scaling measurement"
+    if stub:
+        result["note"] = "STUB: stand-in CPU sampler over gloo (launcher / sharding / JSON contract test) -- not a measurement"
+        result["data"] = "stub"
     total_flops = call_flops(H, L, M, S, T, W, B, C["num_steps"])
     peak = PEAK_TFLOPS[args.dtype]
     result["whole_call"] = {"algorithmic_tflop": total_flops / 1e12, "tflops": world * total_flops / (dt / steps) / 1e12,
                             "frac_of_mfma_peak": total_flops / (dt / steps) / 1e12 / peak, "peak_tflops": peak}
 
-    if extras and not args.no_roofline:
+    if extras and not args.no_roofline and not stub:
         # ---- roofline leg: a SEPARATE loop with the per-launch HIP events on ----
         n_prof = 3 if C["sampler"] == "ddpm" else min(10, steps)
         per_call = C["num_steps"] * L
@@ -305,7 +398,7 @@ def main():
         if traffic:
             gbs = traffic["bytes"] / (avg * 1e-3) / 1e9
             result["roofline"]["hbm"] = {"achieved_GBps": gbs, "peak_GBps": PEAK_HBM_GBS, "frac": gbs / PEAK_HBM_GBS}
-    if extras and not args.no_cpu_baseline and C["sampler"] == "ddim" and args.config in (1, 2):
+    if extras and not stub and not args.no_cpu_baseline and C["sampler"] == "ddim" and args.config in (1, 2):
         result["cpu_baseline"] = cpu_baseline(cfg, sd, min(args.cpu_sample_batch, B), T, C["num_steps"])
 
     if world > 1:

@@ -79,3 +79,43 @@ def test_sharded_generate_gloo(world, total):
         assert p.exitcode == 0
     results = dict(q.get(timeout=5) for _ in range(world))
     assert results == {r: True for r in range(world)}
+
+
+def _run_bench(extra_env, *argv):
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, EDTTS_BENCH_STUB="1", **extra_env)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), *argv], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout  # exactly ONE JSON line, from rank 0
+    return json.loads(lines[0])
+
+
+def test_bench_gpus2_starts_itself():
+    """`python bench.py --gpus 2` with NO outer torchrun (the driver's command form): the parent spawns one rank per GPU before
+    touching any device and relays rank 0's line.  Stub sampler + gloo here (no GPU in this container): the launcher, the
+    sharding, the all-gather, the max-over-ranks timing and the JSON contract are what is exercised."""
+    d = _run_bench({}, "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "4", "--frames", "32")
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["steps"] == 3 and d["warmup"] == 1
+    assert d["scaling"] == "weak" and d["higher_is_better"] is True and d["unit"] == "mel-frames/s"
+    assert d["config"]["batch_per_gpu"] == 4 and d["allgather_bytes"] == 2 * 4 * 32 * 80 * 4 and d["allgather_ms"] > 0
+    assert abs(d["value"] - 2 * 4 * 32 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]  # whole-job aggregate
+
+
+def test_bench_spawned_rank_failure_ends_the_job():
+    """A rank that dies must take the job down with a non-zero status, not leave the others waiting in a collective."""
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, EDTTS_BENCH_STUB="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    # config 5 is refused by the stub on every rank -> all children exit non-zero
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--config", "5", "--steps", "1"], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0
