@@ -36,11 +36,11 @@ typedef float f2v __attribute__((ext_vector_type(2)));
 #ifndef EDTTS_STAMP_THREAD
 #define EDTTS_STAMP_THREAD 0   // first lane of the stamped wave of block 0 (192: wave 3 = frames 96..127, an interior tile)
 #endif
+#undef STAMPX  // (edtts_device.h's form stamps EDTTS_STAMP_BLOCK; the bf16 diagnostics were taken on block 0)
 #define STAMP16(i) do { if (a.stamps && blockIdx.x == 0 && threadIdx.x == EDTTS_STAMP_THREAD) a.stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
 #define STAMPX(p, i) do { if ((p) && blockIdx.x == 0 && threadIdx.x == EDTTS_STAMP_THREAD) (p)[i] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define STAMP16(i) do { } while (0)
-#define STAMPX(p, i) do { } while (0)
 #endif
 
 namespace edtts16 {

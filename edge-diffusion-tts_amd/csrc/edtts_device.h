@@ -17,11 +17,35 @@
 #include <stdint.h>
 #include <type_traits>
 
+// Ablation / diagnostic switches change results or add instrumentation ("wrong by construction"): they exist for scratch/ only and
+// need -DEDTTS_EXPERIMENTS next to them, so that a product build can never carry one by accident.
+#if !defined(EDTTS_EXPERIMENTS) && (defined(EDTTS_ABLATE_QKVSTORES) || defined(EDTTS_ABLATE_KVLOADS) || defined(EDTTS_DIAG) || \
+                                    defined(EDTTS_STAMPS) || defined(EDTTS16_ABLATE_BARRIER) || defined(EDTTS16_ABLATE_DMA) || \
+                                    (defined(EDTTS16_SPLIT_BUILD) && EDTTS16_SPLIT_BUILD))
+#error "ablation / diagnostic / split-layer switches are scratch-only: add -DEDTTS_EXPERIMENTS"
+#endif
+
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef float f2 __attribute__((ext_vector_type(2)));
 
 #define EDTTS_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 #define EDTTS_DEV __device__ __forceinline__
+
+// Diagnostic builds (-DEDTTS_EXPERIMENTS -DEDTTS_STAMPS; scratch/stamps_f32.py, stamps_bf16.py): s_memtime stamps of ONE wave.
+#ifdef EDTTS_STAMPS
+#ifndef EDTTS_STAMP_BLOCK
+#define EDTTS_STAMP_BLOCK 8    // blockIdx.x of the stamped block (8 = logical block 1 after the XCD remap: an interior tile)
+#endif
+#ifndef EDTTS_STAMP_THREAD
+#define EDTTS_STAMP_THREAD 0   // first lane of the stamped wave
+#endif
+#ifndef EDTTS_STAMP_HEAD
+#define EDTTS_STAMP_HEAD 1     // head whose attention steps carry the fine-grained stamps
+#endif
+#define STAMPX(p, i) do { if ((p) && blockIdx.x == EDTTS_STAMP_BLOCK && threadIdx.x == EDTTS_STAMP_THREAD) (p)[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define STAMPX(p, i) do { } while (0)
+#endif
 
 namespace edtts {
 
@@ -45,7 +69,11 @@ struct Cfg {
   static constexpr int MT = MEL / 16;             // feature tiles of the mel dim
   static constexpr int R = H / 2, RT = R / 16;    // kv_lora_rank (transformer.py:113) and its tiles
   static constexpr int VR = (HEADS - 1) * DH + DHP;  // rows of a V^T buffer (last head padded)
-  static constexpr int WAVES = (HT * NF * 4 <= 160) ? 4 : 2;  // waves per block (each parks its residual tile, HT*NF KiB, in LDS)
+#ifndef EDTTS_WMAX
+#define EDTTS_WMAX 4
+#endif
+  static constexpr int WAVES0 = (HT * NF * 4 <= 160) ? 4 : 2;  // waves per block (each parks its residual tile, HT*NF KiB, in LDS)
+  static constexpr int WAVES = WAVES0 < EDTTS_WMAX ? WAVES0 : EDTTS_WMAX;
   // the cross-attention q tile goes through LDS when it fits next to the parked residual tiles (160 KiB per block at H = 160,
   // NF = 2), else through this wave's (already consumed) self-attention q rows in global memory
   static constexpr bool Q_IN_LDS = WAVES * WF * H * 4 * 2 <= 160 * 1024;
@@ -287,7 +315,13 @@ EDTTS_DEV float silu(float g) { return g * __builtin_amdgcn_rcpf(1.0f + __expf(-
 // 6 % slower at B=256, T=512, because its per-phase block barrier costs more than the L2 traffic it saves; see
 // DESIGN.md "What was tried".)
 // Ring size: HT fragments at NF = 2, HT/2 at NF = 4 -- the same prefetch distance in MFMAs (4*NF per fragment).
-template <class C> using WStream = FragRing<((C::HT * 2) / C::NF >= 2 && C::HT % ((C::HT * 2) / C::NF) == 0 ? (C::HT * 2) / C::NF : C::HT)>;
+// Hidden 256 (HT = 16) takes HALF of that: its residual + normalised tiles are 256 registers by themselves, and with a 16-fragment
+// ring the QKV-tail instance spilled (76 B/lane of scratch); 8 fragments = 64 MFMAs of prefetch distance.
+template <class C> constexpr int wstream_ring() {
+  constexpr int full = ((C::HT * 2) / C::NF >= 2 && C::HT % ((C::HT * 2) / C::NF) == 0) ? (C::HT * 2) / C::NF : C::HT;
+  return (C::HT >= 16 && full % 2 == 0) ? full / 2 : full;
+}
+template <class C> using WStream = FragRing<wstream_ring<C>()>;
 
 // acc *= alpha for an MFMA accumulator without exposing VALU arithmetic on it to the compiler.  On the rare rescale path of the
 // online softmax a plain `O *= alpha` makes hipcc hoist 24 v_accvgpr_reads of O into EVERY softmax step (speculatively, above the
@@ -339,7 +373,10 @@ struct VFrag {  // V^T fragments (MFMA A operand of P V) of one chunk of key til
 // ---------------------------------------------------------------------------------------------------------
 template <class C, bool SELF, class QLoad>
 EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, const float* __restrict__ VTb, int ldv,
-                               int nkeys, int window, int m0w, int lane, WStream<C>& ring, f4 (&h)[C::HT][C::NF]) {
+                               int nkeys, int window, int m0w, int lane, WStream<C>& ring, f4 (&h)[C::HT][C::NF],
+                               unsigned long long* stamps = nullptr) {
+  int sidx = 0;  // (EDTTS_STAMPS diagnostic builds: four stamps per step of head EDTTS_STAMP_HEAD)
+  (void)sidx; (void)stamps;
   constexpr int DH = C::DH, DFULL = C::DFULL, DREM = C::DREM, DT = C::DT, H = C::H, CH = kChunk, NF = C::NF;
   constexpr int NHALF = C::NHALF;
   constexpr int QT = C::QT;  // query tiles per half: 2 (32 frames), or 1 in the small-batch instance (NF = 1)
@@ -574,12 +611,18 @@ EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, cons
       using No = std::integral_constant<bool, false>;
       auto step = [&](auto fold_tag, int c, int cnext, KVFrag<C>& KA, VFrag<C>& VA) {  // c: this step's chunk, cnext: the chunk to request into the buffers
         constexpr bool FOLD = decltype(fold_tag)::value;
+#ifdef EDTTS_STAMPS
+        if (hd == EDTTS_STAMP_HEAD) STAMPX(stamps, sidx++);
+#endif
         qk(fold_tag, q, c, KA, qa, qr, S, NM, nm);
         __builtin_amdgcn_sched_barrier(0);
 #ifndef EDTTS_ABLATE_KVLOADS  // timing ablation only
         load_k(q, hd, cnext, KA);  // (the last step re-reads its own tiles)
 #endif
         __builtin_amdgcn_sched_barrier(0);
+#ifdef EDTTS_STAMPS
+        if (hd == EDTTS_STAMP_HEAD) STAMPX(stamps, sidx++);
+#endif
         // one VGPR copy of the scores serves exp2 and the rare rescale (the pin keeps hipcc from re-reading the accumulators
         // after the branch)
         f4 sv[CH][QT];
@@ -650,6 +693,9 @@ EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, cons
 #pragma unroll
         for (int ft = 0; ft < QT; ++ft) lvec[ft] += ps[ft];
         __builtin_amdgcn_sched_barrier(0);
+#ifdef EDTTS_STAMPS
+        if (hd == EDTTS_STAMP_HEAD) STAMPX(stamps, sidx++);
+#endif
 #pragma unroll
         for (int t = 0; t < CH; ++t)
 #pragma unroll
@@ -663,6 +709,9 @@ EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, cons
         load_v(q, hd, cnext, VA);
 #endif
         __builtin_amdgcn_sched_barrier(0);
+#ifdef EDTTS_STAMPS
+        if (hd == EDTTS_STAMP_HEAD) STAMPX(stamps, sidx++);
+#endif
       };
       // step s = 0: the diagonal chunk; steps 1 .. nchunk-1: the other chunks in ascending order
       const int cd = q.cdiag;
@@ -687,12 +736,18 @@ EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, cons
       }
     }
     // ---- project: h[nt] += Wo[:, head features] . O  (all NF frame tiles at once) ------------------------------------
+#ifdef EDTTS_STAMPS
+    if (hd == EDTTS_STAMP_HEAD) STAMPX(stamps, sidx++);  // (normalisation done: start of the projection phases)
+#endif
     if (hd + 1 < C::HEADS) prefetch(geo[0], hd + 1, 0);
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) {
       if (DREM && dt == DT - 1) ktile_phase<C::HT, WStream<C>::RN_, NF, 2>(ring, O[dt], h);  // remainder tile: valid k in steps 0, 1 only
       else ktile_phase<C::HT>(ring, O[dt], h);
     }
+#ifdef EDTTS_STAMPS
+    if (hd == EDTTS_STAMP_HEAD) STAMPX(stamps, sidx++);  // end of the head
+#endif
   }
 }
 

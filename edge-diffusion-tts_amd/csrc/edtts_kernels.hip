@@ -51,6 +51,7 @@ static int fail(int code, const char* fmt, ...) {
 // =========================================================================================================
 // optional per-launch timing of the dominant kernel (bench.py roofline leg)
 // =========================================================================================================
+#include <initializer_list>
 #include <vector>
 struct Profiler {
   std::vector<hipEvent_t> start, stop;
@@ -668,6 +669,7 @@ __global__ __launch_bounds__(C::THREADS) void k_layer(KArgs a) {
   float* qtile = smem + (size_t)C::WAVES * C::HT * NF * 256 + (size_t)wave * C::WF * QLDS;  // (only touched when C::Q_IN_LDS)
   const size_t rowbase = (size_t)b * a.Tp + m0 + fq;
 
+  STAMPX(a.stamps, 0);
   WStream<C> ring;
   ring.prime(a.stream, lane);
 
@@ -715,9 +717,10 @@ __global__ __launch_bounds__(C::THREADS) void k_layer(KArgs a) {
     if (DIAG_ON(1)) {
       QGlobal ql{a.q + rowbase * C::H, C::H};
       attention_fused<C, true>(ql, a.k + (size_t)b * a.Tp * C::H, a.vT + (size_t)b * C::VR * a.Tp, a.Tp, a.T, a.window, m0,
-                               lane, ring, h);
+                               lane, ring, h, a.stamps ? a.stamps + 8 : nullptr);
     }
     add_parked_h();
+    STAMPX(a.stamps, 1);
   } else {
 #pragma unroll
     for (int nt = 0; nt < C::HT; ++nt)
@@ -746,6 +749,7 @@ __global__ __launch_bounds__(C::THREADS) void k_layer(KArgs a) {
           }
       }
     }
+    STAMPX(a.stamps, 2);
 #pragma unroll
     for (int nt = 0; nt < C::HT; ++nt)
 #pragma unroll
@@ -753,13 +757,14 @@ __global__ __launch_bounds__(C::THREADS) void k_layer(KArgs a) {
     if constexpr (C::Q_IN_LDS) {
       QLds ql{qtile + fq * QLDS, QLDS};
       attention_fused<C, false>(ql, a.kc + (size_t)b * a.Sp * C::H, a.vcT + (size_t)b * C::VR * a.Sp, a.Sp, a.S, -1, m0, lane,
-                                ring, h);
+                                ring, h, a.stamps ? a.stamps + 40 : nullptr);
     } else {
       QGlobal ql{a.q + rowbase * C::H, C::H};
       attention_fused<C, false>(ql, a.kc + (size_t)b * a.Sp * C::H, a.vcT + (size_t)b * C::VR * a.Sp, a.Sp, a.S, -1, m0, lane,
                                 ring, h);
     }
     add_parked_h();
+    STAMPX(a.stamps, 3);
   }
   if (PART == PART_ATTN) {  // hand the residual tile to the FFN half
     park_h();
@@ -808,6 +813,7 @@ __global__ __launch_bounds__(C::THREADS) void k_layer(KArgs a) {
       ktile_phase<C::HT>(ring, act, h);
     }
     add_parked_h();
+    STAMPX(a.stamps, 4);
   }
   // ---- tail ---------------------------------------------------------------------------------------------------
   if (!DIAG_ON(8)) return;
@@ -842,6 +848,11 @@ __global__ __launch_bounds__(C::THREADS) void k_layer(KArgs a) {
       }
     }
   }
+  STAMPX(a.stamps, 5);
+#ifdef EDTTS_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // stores drained
+#endif
+  STAMPX(a.stamps, 6);
 }
 
 #include "edtts_bf16.h"
@@ -1150,7 +1161,14 @@ struct StepArgs {
   size_t n_per_batch;
   float eta;
   float *x_prev, *x0;
+  int vec4;  // 1: n_per_batch % 4 == 0 and every tensor 16-byte aligned -> float4 accesses; 0: scalar path
 };
+// the float4 path of the stand-alone update kernels needs every batch row base 16-byte aligned
+static int step_vec4(size_t n_per_batch, std::initializer_list<const void*> ptrs) {
+  uintptr_t m = 0;
+  for (const void* p : ptrs) m |= (uintptr_t)p;
+  return (n_per_batch & 3) == 0 && (m & 15) == 0;
+}
 EDTTS_DEV long clamp_idx(long v, int n) { return v < 0 ? 0 : (v >= n ? n - 1 : v); }
 
 __global__ __launch_bounds__(256) void k_ddim(StepArgs a) {
@@ -1162,7 +1180,7 @@ __global__ __launch_bounds__(256) void k_ddim(StepArgs a) {
   const DdimCoef cf = ddim_coef(ab, abp, a.eta);
   const float s1m = cf.s1m, sab = cf.sab, sabp = cf.sabp, cdir = cf.cdir, sigma = cf.sigma;
   const size_t base = (size_t)b * a.n_per_batch;
-  const size_t n4 = a.n_per_batch >> 2;
+  const size_t n4 = a.vec4 ? a.n_per_batch >> 2 : 0;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
     const size_t o = base + 4 * i;
     const f4 xv = ldg4(a.x + o), e = ldg4(a.eps + o);
@@ -1180,9 +1198,9 @@ __global__ __launch_bounds__(256) void k_ddim(StepArgs a) {
     stg4(a.x0 + o, x0);
     stg4(a.x_prev + o, xp);
   }
-  // ragged tail (n_per_batch % 4) -- never hit for n_mels % 4 == 0, kept for generality
-  if (blockIdx.x == 0 && threadIdx.x < (a.n_per_batch & 3)) {
-    const size_t o = base + (n4 << 2) + threadIdx.x;
+  // scalar path: everything when n_per_batch % 4 != 0 or a tensor is not 16-byte aligned (never on the sampler's own tensors)
+  for (size_t i = (n4 << 2) + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n_per_batch; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t o = base + i;
     float v, p;
     ddim_elem(a.x[o], a.eps[o], s1m, sab, sabp, cdir, v, p);
     if (a.noise) p = add_mul_rn(p, sigma, a.noise[o]);
@@ -1197,7 +1215,7 @@ __global__ __launch_bounds__(256) void k_ddpm(StepArgs a) {
   const float al = a.alphas[tt], ab = a.alpha_bar[tt], be = a.betas[tt];
   const DdpmCoef cf = ddpm_coef(al, ab, be, a.post_var[tt], (long)a.t[b] > 0);
   const size_t base = (size_t)b * a.n_per_batch;
-  const size_t n4 = a.n_per_batch >> 2;
+  const size_t n4 = a.vec4 ? a.n_per_batch >> 2 : 0;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
     const size_t o = base + 4 * i;
     const f4 xv = ldg4(a.x + o), e = ldg4(a.eps + o), nz = ldg4(a.noise + o);
@@ -1206,8 +1224,8 @@ __global__ __launch_bounds__(256) void k_ddpm(StepArgs a) {
     for (int r = 0; r < 4; ++r) xp[r] = ddpm_elem(xv[r], e[r], nz[r], cf);
     stg4(a.x_prev + o, xp);
   }
-  if (blockIdx.x == 0 && threadIdx.x < (a.n_per_batch & 3)) {  // ragged tail (n_per_batch % 4)
-    const size_t o = base + (n4 << 2) + threadIdx.x;
+  for (size_t i = (n4 << 2) + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n_per_batch; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t o = base + i;  // scalar path (see k_ddim)
     a.x_prev[o] = ddpm_elem(a.x[o], a.eps[o], a.noise[o], cf);
   }
 }
@@ -1387,10 +1405,14 @@ static void make_workspace(const Layout& lo, int B, int T, int S, int cond_rows,
   w->total = o;
 }
 
+// Philox stream ids (the `step` word of the counter) are split into disjoint domains so that no two draws of one seed can meet
+// (include/edtts.h, "Philox stream ids"): [0, 0x10000) belongs to edtts_randn callers, the samplers' per-step draws live above it.
+constexpr unsigned kStreamDdpmStep = 0x10000u;     // + step index: ancestral noise of edtts_sample_ddpm
+constexpr unsigned kStreamInpaintStep = 0x20000u;  // + step index: q_sample noise of edtts_sample_inpaint's known frames
 struct DdpmStepArgs {
   const float* noise;
   unsigned long long seed, base;
-  unsigned step;
+  unsigned step;  // stream id (kStreamDdpmStep + step index)
 };
 struct VpredStepArgs {
   VpredCoef k;
@@ -1402,6 +1424,9 @@ struct LmsStepArgs {
   float *x0_hist, *x0_all;
 };
 
+#ifdef EDTTS_STAMPS
+static unsigned long long* g_stamps_fwd = nullptr;  // diagnostic builds only, see edtts_debug_set_stamps
+#endif
 template <class C>
 struct Launcher {
   static size_t ring_lds() { return 0; }
@@ -1505,7 +1530,10 @@ struct Launcher {
         a.x_prev = x_prev; a.x0 = x0;
         a.c_s1m = coef[0]; a.c_sab = coef[1]; a.c_sabp = coef[2]; a.c_dir = coef[3];
       }
-      if (SPLIT) {
+#ifdef EDTTS_STAMPS
+      a.stamps = g_stamps_fwd ? g_stamps_fwd + 128 * l : nullptr;
+#endif
+      if constexpr (SPLIT) {  // (not instantiated in the product build: EDTTS_NF_FFN defaults to the instance's own NF)
         static_assert(!SPLIT, "the two-launch layer experiment predates the LDS-parked residual tile (see git history)");
         g_prof.kind = 0;
         PROF_LAUNCH(st, hipLaunchKernelGGL((k_layer<C, TAIL_QKV, PART_ATTN>), dim3(g), dim3(C::THREADS), layer_lds(), st, a));
@@ -1554,7 +1582,7 @@ struct Launcher {
       if (rc) return rc;
     }
     const int lds = (int)layer_lds();
-    if (SPLIT) {
+    if constexpr (SPLIT) {
       HIP_TRY(hipFuncSetAttribute((const void*)k_layer<C, TAIL_QKV, PART_ATTN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     } else {
       HIP_TRY(hipFuncSetAttribute((const void*)k_layer<C, TAIL_QKV, PART_ALL>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -1569,9 +1597,6 @@ struct Launcher {
   }
 };
 
-#ifdef EDTTS_STAMPS
-static unsigned long long* g_stamps_fwd = nullptr;  // diagnostic builds only, see edtts_debug_set_stamps
-#endif
 // ---- bf16 instance (edtts_bf16.h) ----------------------------------------------------------------------------
 // frame tiles per wave of the hidden-256 bf16 instance: 2 = four waves per block, 1 = eight (two per SIMD)
 #ifndef EDTTS16_NF
@@ -2037,7 +2062,7 @@ int edtts_sample_ddpm(const EdttsDims* dims, const void* packed, void* workspace
     TRY(LN::ctx(lo, blob, ws, wsb, B, S, sem_idx, nullptr, st));
     for (int i = 0; i < num_steps; ++i) {
       typename LN::DdpmStep ds{noise_all ? noise_all + (size_t)i * per_step : nullptr, (unsigned long long)seed,
-                                        (unsigned long long)batch_offset * T * lo.MEL, (unsigned)i};
+                                        (unsigned long long)batch_offset * T * lo.MEL, kStreamDdpmStep + (unsigned)i};
       TRY(LN::forward(lo, blob, ws, wsb, B, T, S, dims->window, i == 0 ? x_T : x_out, wsb + ws.cond + i * row, 0, TAIL_DDPM,
                                nullptr, x_out, nullptr, coef_host + 3 * i, st, &ds));
     }
@@ -2089,7 +2114,7 @@ int edtts_sample_inpaint(const EdttsDims* dims, const void* packed, void* worksp
     if (bx > 2048) bx = 2048;
     hipLaunchKernelGGL(k_inpaint_inject, dim3((unsigned)bx), dim3(256), 0, st, x, known_mel,
                        noise_k ? noise_k + (size_t)step * B * overlap_len * lo.MEL : nullptr, B, T, overlap_len, lo.MEL, ck, cn,
-                       (unsigned long long)seed, (unsigned)step);
+                       (unsigned long long)seed, kStreamInpaintStep + (unsigned)step);
   };
   EDTTS_DISPATCH(lo, {
     TRY(LN::set_attrs());
@@ -2129,7 +2154,8 @@ int edtts_ddim_step(const float* alpha_bar, int n_table, const float* x, const f
   memset(&a, 0, sizeof(a));
   a.alpha_bar = alpha_bar; a.n_table = n_table; a.x = x; a.eps = eps; a.t = t; a.t_prev = t_prev;
   a.n_per_batch = n_per_batch; a.eta = eta; a.noise = eta > 0.f ? noise : nullptr; a.x_prev = x_prev; a.x0 = x0;
-  size_t bx = (n_per_batch / 4 + 255) / 256;
+  a.vec4 = step_vec4(n_per_batch, {x, eps, a.noise, x_prev, x0});
+  size_t bx = ((a.vec4 ? n_per_batch / 4 : n_per_batch) + 255) / 256;
   if (bx > 2048) bx = 2048;
   if (bx < 1) bx = 1;
   hipLaunchKernelGGL(k_ddim, dim3((unsigned)bx, B), dim3(256), 0, (hipStream_t)stream, a);
@@ -2146,9 +2172,8 @@ int edtts_ddpm_step(const float* alphas, const float* alpha_bar, const float* be
   memset(&a, 0, sizeof(a));
   a.alphas = alphas; a.alpha_bar = alpha_bar; a.betas = betas; a.post_var = post_var; a.n_table = n_table;
   a.x = x; a.eps = eps; a.t = t; a.n_per_batch = n_per_batch; a.noise = noise; a.x_prev = x_prev;
-  if ((n_per_batch & 3) && (((uintptr_t)x | (uintptr_t)eps | (uintptr_t)noise | (uintptr_t)x_prev) & 15))
-    return fail(EDTTS_ERR_ARG, "tensors must be 16-byte aligned");
-  size_t bx = (n_per_batch / 4 + 255) / 256;
+  a.vec4 = step_vec4(n_per_batch, {x, eps, noise, x_prev});
+  size_t bx = ((a.vec4 ? n_per_batch / 4 : n_per_batch) + 255) / 256;
   if (bx > 2048) bx = 2048;
   if (bx < 1) bx = 1;
   hipLaunchKernelGGL(k_ddpm, dim3((unsigned)bx, B), dim3(256), 0, (hipStream_t)stream, a);
@@ -2186,9 +2211,11 @@ __global__ __launch_bounds__(256) void k_randn(float* out, size_t n, unsigned lo
 }
 
 int edtts_randn(float* out, size_t n, uint64_t seed, uint32_t stream_id, uint64_t elem_offset, float scale, void* stream) {
-  if (!out) return fail(EDTTS_ERR_ARG, "NULL pointer argument");
   if ((n & 3) || (elem_offset & 3)) return fail(EDTTS_ERR_ARG, "n=%zu and elem_offset=%llu must be multiples of 4", n, (unsigned long long)elem_offset);
-  if (n == 0) return EDTTS_OK;
+  if (stream_id >= kStreamDdpmStep) return fail(EDTTS_ERR_ARG, "stream_id %u is reserved for the samplers' per-step draws (>= 0x10000)", stream_id);
+  if (n == 0) return EDTTS_OK;  // an empty shard (fewer utterances than ranks): its zero-element tensor has a NULL data pointer
+  if (!out) return fail(EDTTS_ERR_ARG, "NULL pointer argument");
+  if ((uintptr_t)out & 15) return fail(EDTTS_ERR_ARG, "out must be 16-byte aligned");
   size_t bx = (n / 4 + 255) / 256;
   if (bx > 4096) bx = 4096;
   hipLaunchKernelGGL(k_randn, dim3((unsigned)bx), dim3(256), 0, (hipStream_t)stream, out, n, (unsigned long long)seed, (unsigned)stream_id,

@@ -62,6 +62,7 @@ class EdgeDiffusionDecoder(nn.Module):
         self._packed: Optional[torch.Tensor] = None
         self._packed_sig: Optional[Tuple] = None
         self._workspaces: Dict[Tuple, torch.Tensor] = {}
+        self._pinned_workspaces = set()  # keys handed out during graph capture (never evicted)
 
     # same distributions as the reference's default construction (nn.Linear / nn.Embedding defaults, ones for norm
     # gains, zeros for final out_proj and the AdaLN projections -- decoder.py:63-64, transformer.py:61-62)
@@ -178,15 +179,23 @@ class EdgeDiffusionDecoder(nn.Module):
             self._packed_sig = sig
         return self._packed
 
+    WORKSPACE_CACHE = 8
+
     def workspace(self, B: int, T: int, S: int, cond_rows: int, device, tag: str = "") -> torch.Tensor:
+        """Cached scratch memory for one (shape, device, tag).  At most WORKSPACE_CACHE entries are kept; the least recently USED one
+        is dropped to make room -- never one that a captured hipGraph points at (a workspace handed out while the stream was
+        capturing is pinned for the life of the decoder: a replay writes into it)."""
         key = (B, T, S, cond_rows, str(device), tag)
-        ws = self._workspaces.get(key)
+        ws = self._workspaces.pop(key, None)
         if ws is None:
-            if len(self._workspaces) >= 6:
-                self._workspaces.clear()
+            evictable = [k for k in self._workspaces if k not in self._pinned_workspaces]  # insertion order = least recently used first
+            while len(self._workspaces) >= self.WORKSPACE_CACHE and evictable:
+                del self._workspaces[evictable.pop(0)]
             nbytes = native.workspace_bytes(self.dims(), B, T, S, cond_rows)
             ws = torch.zeros(nbytes, dtype=torch.uint8, device=device)  # must start zero-filled (padding lanes)
-            self._workspaces[key] = ws
+        self._workspaces[key] = ws  # (re-)inserted last = most recently used
+        if ws.is_cuda and torch.cuda.is_current_stream_capturing():
+            self._pinned_workspaces.add(key)
         return ws
 
     # ------------------------------------------------------------------------------------------ forward

@@ -6,7 +6,8 @@ context with a constant step index, q_sample of the previous chunk's tail forced
 step, optional classifier-free guidance against an all-zero context), each running as ONE C-ABI call
 (include/edtts.h: edtts_sample_inpaint): context K/V built once per call (twice with guidance), the blend is a tiny elementwise
 kernel, guidance combine + x0 / eps / next-x update are fused into the last transformer layer.  ``generate_long`` is the
-reference's chunk loop (sequential: every chunk is conditioned on the tail of the previous one) with its linear cross-fade.
+reference's chunk loop (:296-367) as written: per-chunk de-normalisation, exp, cross-fade of LINEAR mels with the trapezoid
+window, division by the summed weights (sequential: every chunk is conditioned on the tail of the previous one).
 """
 from __future__ import annotations
 
@@ -108,36 +109,84 @@ class InpaintSampler:
         times = linspace_times(t_start, steps)
         return self._run(x, sem_features, times, 0, known_mel, overlap_len if known_mel is not None else 0, cfg_scale, noise_k, seed)
 
+    @staticmethod
+    def latent_slices(n_chunks: int, hop_samples: int, chunk_samples: int, sample_rate: int) -> List[tuple]:
+        """Per-chunk [start_lat, end_lat) into the global semantic features (inference_pipeline.py:308-317): sample position ->
+        seconds -> 16 kHz sample -> HuBERT frame (320 samples each), with the reference's float arithmetic and truncations."""
+        out = []
+        for i in range(n_chunks):
+            start_sample = i * hop_samples
+            end_sample = start_sample + chunk_samples
+            out.append((int(start_sample / sample_rate * 16000) // 320, int(end_sample / sample_rate * 16000) // 320))
+        return out
+
     @torch.no_grad()
     def generate_long(self, sem_features: torch.Tensor, total_frames: int, chunk_frames: int, overlap_frames: int,
-                      lat_per_frame: float = 0.5, strength: float = 0.999, steps: int = 10, cfg_scale: float = 1.0,
-                      seed: int = 0) -> torch.Tensor:
-        """The reference's sliding-window loop (inference_pipeline.py:296-361) on normalised mels: chunk i is refined from noise
-        with the teacher sampler, conditioned on the last ``overlap_frames`` frames of chunk i-1 (in-painting), and the chunks are
-        cross-faded with the reference's linear window.  ``sem_features`` [1, S_total, semantic_dim] are the global semantic
-        features; chunk i sees the slice that covers its frames (``lat_per_frame`` latents per mel frame).  Returns
-        [1, total_frames, n_mels].  (De-normalisation / exp / vocoding follow in melpost.py.)"""
+                      chunk_stats, *, strength: float = 0.999, steps: int = 10, cfg_scale: float = 1.0, seed: int = 0,
+                      latent_slices: Optional[List[tuple]] = None, hop_length: Optional[int] = None,
+                      sample_rate: Optional[int] = None, draws: Optional[List[dict]] = None) -> torch.Tensor:
+        """The reference's context-aware sliding window (inference_pipeline.py:296-367), statement for statement:
+
+            for chunk i (hop = chunk_frames - overlap_frames frames apart):
+                z_q_chunk   = sem_features[:, start_lat:end_lat]                                         (:308-325)
+                x_refined   = inpaint_teacher_refine(randn, z_q_chunk, known_mel=prev_mel_tail, overlap_len=overlap_frames, ...)
+                prev_tail   = x_refined[:, -overlap_frames:]                                             (:346)
+                mel_denorm  = denormalize_mel(x_refined, mean_i, std_i)         per-chunk statistics     (:349-352)
+                lin_mel     = exp(mel_denorm)^T                                  LINEAR mel [n_mels, T]   (:353)
+                final[:, f0:f0+chunk] += lin_mel * window ;  weights[:, f0:f0+chunk] += window           (:360-361)
+            final = (final / clamp(weights, 1e-5))[:, :total_frames]                                     (:364-367)
+
+        with the trapezoid window of :253-260 (linear fade-in over the first and fade-out over the last ``overlap_frames``
+        frames).  Returns the stitched LINEAR mel [n_mels, total_frames] -- what the reference hands to its smoothing /
+        InverseMelScale / Griffin-Lim tail (melpost.py).
+
+        ``chunk_stats``: one (mean, std) pair per chunk, each broadcastable to [1, 1, n_mels] -- the reference takes them from the
+        ground-truth audio of the chunk (normalize_mel of its log-mel, :349-351); that audio front end (torchaudio) is outside the
+        path, so the caller supplies the numbers.  ``latent_slices``: the per-chunk [start, end) rows of ``sem_features``; by
+        default computed from ``hop_length`` / ``sample_rate`` (cfg values) exactly as the reference does.  ``draws`` (parity
+        tests): per chunk a dict with the reference's torch.randn draws ``x_coarse``, ``noise`` and (chunks with a known tail)
+        ``noise_k``; otherwise they come from the library's Philox streams.
+        The chunk loop is sequential by construction (chunk i is conditioned on the tail of chunk i-1)."""
         dev = sem_features.device
         M = self.cfg.n_mels
-        hop = chunk_frames - overlap_frames
-        n_chunks = max(1, -(-(total_frames - overlap_frames) // hop))
-        final = torch.zeros(1, total_frames + chunk_frames, M, device=dev)
-        weights = torch.zeros(1, total_frames + chunk_frames, 1, device=dev)
-        window = torch.ones(chunk_frames, device=dev)
-        window[:overlap_frames] = torch.linspace(0, 1, overlap_frames, device=dev)
-        window[-overlap_frames:] = torch.linspace(1, 0, overlap_frames, device=dev)
+        if not 0 <= overlap_frames < chunk_frames:
+            raise ValueError(f"need 0 <= overlap_frames < chunk_frames, got {overlap_frames} / {chunk_frames}")
+        hop_frames = chunk_frames - overlap_frames
+        hop_length = int(hop_length if hop_length is not None else self.cfg.hop_length)
+        sample_rate = int(sample_rate if sample_rate is not None else self.cfg.sample_rate)
+        chunk_samples, overlap_samples = chunk_frames * hop_length, overlap_frames * hop_length
+        hop_samples = chunk_samples - overlap_samples
+        total_samples = total_frames * hop_length
+        n_chunks = max(1, -(-(total_samples - overlap_samples) // hop_samples))  # int(np.ceil(...)), :225
+        if len(chunk_stats) != n_chunks:
+            raise ValueError(f"chunk_stats must hold {n_chunks} (mean, std) pairs, got {len(chunk_stats)}")
+        if latent_slices is None:
+            latent_slices = self.latent_slices(n_chunks, hop_samples, chunk_samples, sample_rate)
+        estimated = total_frames + 1000  # :227 (room for the last, ragged chunk)
+        if (n_chunks - 1) * hop_frames + chunk_frames > estimated:
+            raise ValueError("chunk geometry exceeds the reference's stitching buffer (total_frames + 1000 frames)")
+        final = torch.zeros(M, estimated, device=dev)
+        weights = torch.zeros(1, estimated, device=dev)
+        window = torch.ones(1, chunk_frames, device=dev)
+        if overlap_frames > 0:  # (:253-260; with no overlap the window is flat and no tail is handed on)
+            window[0, :overlap_frames] = torch.linspace(0, 1, overlap_frames, device=dev)
+            window[0, -overlap_frames:] = torch.linspace(1, 0, overlap_frames, device=dev)
         prev_tail = None
         for i in range(n_chunks):
-            f0 = i * hop
-            l0 = int(f0 * lat_per_frame)
-            l1 = max(int((f0 + chunk_frames) * lat_per_frame), l0 + 1)
-            z = sem_features[:, l0:l1]
+            l0, l1 = latent_slices[i]
+            z = sem_features[:, l0:l1].contiguous()
             if z.shape[1] == 0:
-                break
-            x_coarse = native.randn((1, chunk_frames, M), dev, seed=seed + 2 * i + 1, stream_id=0x53)
-            x = self.inpaint_teacher_refine(x_coarse, z.contiguous(), prev_tail, overlap_frames, strength, steps, cfg_scale,
-                                            seed=seed + 2 * i)
-            prev_tail = x[:, -overlap_frames:].clone()
-            final[:, f0:f0 + chunk_frames] += x * window[None, :, None]
-            weights[:, f0:f0 + chunk_frames] += window[None, :, None]
-        return (final / weights.clamp(min=1e-5))[:, :total_frames]
+                raise ValueError(f"chunk {i}: empty semantic slice [{l0}:{l1}] of {sem_features.shape[1]} rows")
+            d = draws[i] if draws is not None else {}
+            x_coarse = d["x_coarse"].to(dev) if "x_coarse" in d else native.randn((1, chunk_frames, M), dev, seed=seed + 2 * i + 1, stream_id=0x53)
+            x = self.inpaint_teacher_refine(x_coarse, z, prev_tail, overlap_frames if prev_tail is not None else 0, strength, steps,
+                                            cfg_scale, noise=d.get("noise"), noise_k=d.get("noise_k"), seed=seed + 2 * i)
+            prev_tail = x[:, -overlap_frames:].clone() if overlap_frames > 0 else None
+            mean, std = chunk_stats[i]
+            mean = torch.as_tensor(mean, dtype=torch.float32, device=dev)
+            std = torch.as_tensor(std, dtype=torch.float32, device=dev)
+            lin = torch.exp(x * std + mean).transpose(1, 2).squeeze(0)  # utils/audio.py:17-19, then :353-354
+            f0 = i * hop_frames
+            final[:, f0:f0 + chunk_frames] += lin * window
+            weights[:, f0:f0 + chunk_frames] += window
+        return (final / torch.clamp(weights, min=1e-5))[:, :total_frames]

@@ -247,6 +247,8 @@ def randn(shape, device, seed: int = 0, stream_id: int = 0, elem_offset: int = 0
     out = torch.empty(tuple(shape), dtype=torch.float32, device=device)
     if not out.is_cuda:
         raise EdttsError(f"randn: expected a HIP device, got {out.device} -- the MI355X sampler path has no CPU fallback")
+    if out.numel() == 0:  # the empty shard of a rank without utterances: nothing to draw (data_ptr() is NULL)
+        return out
     lib().edtts_randn(out.data_ptr(), out.numel(), C.c_uint64(seed & 0xFFFFFFFFFFFFFFFF), C.c_uint32(stream_id & 0xFFFFFFFF),
                       C.c_uint64(int(elem_offset)), float(scale), _stream(out.device))
     return out

@@ -124,7 +124,10 @@ class ShardedEdgeInference:
             m = n_mels if n_mels is not None else self.infer.cfg.n_mels
             if sem_idx.is_cuda:
                 from . import native
-                x_loc = native.randn((hi - lo, 2 * S, m), sem_idx.device, seed, 0, lo * 2 * S * m, temperature)
+                if hi > lo:
+                    x_loc = native.randn((hi - lo, 2 * S, m), sem_idx.device, seed, 0, lo * 2 * S * m, temperature)
+                else:  # this rank owns no utterance: no draw, an empty shard for the gather
+                    x_loc = torch.empty((0, 2 * S, m), dtype=torch.float32, device=sem_idx.device)
                 x_T = _LocalRows(x_loc, lo, hi, B)
             else:
                 g = torch.Generator(device=sem_idx.device).manual_seed(seed)

@@ -111,14 +111,16 @@ int edtts_decoder_forward(const EdttsDims* dims, const void* packed, void* works
 /* ---- DDIM update  (schedule.py:157-202, DiffusionSchedule.get_ddim_step) --------------------------------
  * alpha_bar [n_table] fp32 table; t, t_prev [B] int64 (t_prev < 0 -> alpha_bar_prev = 1); n_per_batch =
  * T*n_mels; eta >= 0; noise [B,T,n_mels] or NULL (required when eta > 0).  Writes x_prev and x0 (clamped
- * to [-3,3]).  Same operation order as the reference: division by sqrt(ab), direction from the raw eps. */
+ * to [-3,3]).  Same operation order as the reference: division by sqrt(ab), direction from the raw eps.
+ * Alignment: with n_per_batch % 4 == 0 and all tensors 16-byte aligned the kernel moves float4s; any other combination takes a
+ * scalar path with identical results (no alignment requirement on the caller). */
 int edtts_ddim_step(const float* alpha_bar, int n_table, const float* x, const float* eps, const int64_t* t,
                     const int64_t* t_prev, int B, size_t n_per_batch, float eta, const float* noise,
                     float* x_prev, float* x0, void* stream);
 
 /* ---- DDPM update  (schedule.py:204-238, DiffusionSchedule.ddpm_step) ------------------------------------
  * tables: alphas, alpha_bar, betas, posterior_variance [n_table]; noise [B,T,n_mels] is the draw the
- * reference takes from torch.randn_like (the host supplies it). */
+ * reference takes from torch.randn_like (the host supplies it).  Alignment: as edtts_ddim_step. */
 int edtts_ddpm_step(const float* alphas, const float* alpha_bar, const float* betas, const float* post_var,
                     int n_table, const float* x, const float* eps, const int64_t* t, int B, size_t n_per_batch,
                     const float* noise, float* x_prev, void* stream);
@@ -157,7 +159,16 @@ int edtts_sample_ddpm(const EdttsDims* dims, const void* packed, void* workspace
 /* ---- start noise  (inference.py:33: torch.randn(B, T_out, n_mels) * temperature) ---------------------------------
  * out[i] = scale * N(0,1) drawn from the Philox4x32-10 stream (seed, stream_id) at GLOBAL element index elem_offset + i, for
  * i in [0, n): a rank that owns rows [lo, hi) of a batch passes elem_offset = lo*T*n_mels and gets exactly the values a
- * single GPU would draw for those rows (shard-count-invariant, no global draw).  n and elem_offset multiples of 4. */
+ * single GPU would draw for those rows (shard-count-invariant, no global draw).  n and elem_offset multiples of 4; n = 0 is a
+ * no-op (out may be NULL then: the empty shard of a rank that has no utterances).
+ *
+ * Philox stream ids.  Every draw of the library is keyed (seed, stream id, global element).  The id space is split so that two
+ * draws made with one seed can never coincide:
+ *     [0x00000, 0x10000)  edtts_randn callers (0 = start noise of generate_mel / sample_ddpm; the host-side long-form sampler
+ *                         uses 0x51 start noise, 0x52 q_sample noise of the teacher refinement, 0x53 per-chunk coarse noise)
+ *     0x10000 + step      ancestral noise of step `step` inside edtts_sample_ddpm
+ *     0x20000 + step      q_sample noise of the known frames at step `step` inside edtts_sample_inpaint
+ * edtts_randn rejects stream_id >= 0x10000. */
 int edtts_randn(float* out, size_t n, uint64_t seed, uint32_t stream_id, uint64_t elem_offset, float scale, void* stream);
 
 /* ---- multistep x0-solver sampler  (schedule.py:440-527, DPMSolverPP.sample with the updates of :339-438) -------

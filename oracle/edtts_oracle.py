@@ -420,6 +420,34 @@ def inpaint_teacher_refine(sd: SD, tabs, x_coarse, sem_features, noise, known_me
     return inpaint_loop(sd, tabs, x, sem_features, linspace_times(t_start, steps), 0, known_mel, overlap_len, noise_k, cfg_scale, **kw)
 
 
+def longform_stitch(sd: SD, tabs, sem_features: Tensor, total_frames: int, chunk_frames: int, overlap_frames: int, chunk_stats,
+                    latent_slices, draws, strength: float, steps: int, cfg_scale: float, **kw) -> Tensor:
+    """inference_pipeline.py:296-367 -- the sliding-window loop and the stitch: chunk i = inpaint_teacher_refine conditioned on the
+    last `overlap_frames` frames of chunk i-1 (:329-346); denormalize_mel with the chunk's (mean, std) (:349-352, utils/audio.py:17-19);
+    exp -> LINEAR mel, transposed to [n_mels, frames] (:353-354); accumulated under the trapezoid window of :253-260 at frame
+    i * (chunk_frames - overlap_frames) (:357-361); divided by the clamped sum of the windows and trimmed (:364-367).
+    draws[i] = {x_coarse, noise, noise_k?}: the chunk's torch.randn draws.  Pinned by tests/golden/longform_stitch.npz (the
+    reference's own loop statement run on its own closures)."""
+    M = draws[0]["x_coarse"].shape[-1]
+    hop = chunk_frames - overlap_frames
+    final = torch.zeros(M, total_frames + 1000)
+    weights = torch.zeros(1, total_frames + 1000)
+    window = torch.ones(1, chunk_frames)
+    window[0, :overlap_frames] = torch.linspace(0, 1, overlap_frames)
+    window[0, -overlap_frames:] = torch.linspace(1, 0, overlap_frames)
+    prev_tail = None
+    for i, (l0, l1) in enumerate(latent_slices):
+        d = draws[i]
+        x = inpaint_teacher_refine(sd, tabs, d["x_coarse"], sem_features[:, l0:l1], d["noise"], prev_tail,
+                                   overlap_frames if prev_tail is not None else 0, strength, steps, cfg_scale, d.get("noise_k"), **kw)
+        prev_tail = x[:, -overlap_frames:].clone()
+        mean, std = chunk_stats[i]
+        lin = torch.exp(x * std + mean).transpose(1, 2).squeeze(0)
+        final[:, i * hop: i * hop + chunk_frames] += lin * window
+        weights[:, i * hop: i * hop + chunk_frames] += window
+    return (final / torch.clamp(weights, min=1e-5))[:, :total_frames]
+
+
 # ------------------------------------------------------------------------------------------------
 # mel post-processing (SURVEY.md section 8f row 3): denormalise -> exp -> InverseMelScale -> Griffin-Lim
 #

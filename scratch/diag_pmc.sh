@@ -1,7 +1,7 @@
 #!/bin/bash
 # diagnostic: SQ counters of k_layer with only one phase active (EDTTS_DIAG build)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-hipcc -O3 -std=c++17 --offload-arch=gfx950 -shared -fPIC -DEDTTS_DIAG edge-diffusion-tts_amd/csrc/edtts_kernels.hip -o /tmp/libedtts_diag.so
+hipcc -O3 -std=c++17 --offload-arch=gfx950 -shared -fPIC -DEDTTS_EXPERIMENTS -DEDTTS_DIAG edge-diffusion-tts_amd/csrc/edtts_kernels.hip -o /tmp/libedtts_diag.so
 for skip in 14 13 11 7 0; do
   EDTTS_LIB=/tmp/libedtts_diag.so EDTTS_DIAG_SKIP=$skip rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA --output-format csv -d gpurun_out/diagpmc/s$skip -o pmc -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
 done

@@ -44,6 +44,27 @@ def test_ddim_ddpm_bit_exact(golden):
     xd = sch.ddpm_step(cu(g["x"]), cu(g["t"]), cu(g["eps"]), noise=cu(g["ddpm_noise"]))
     assert torch.equal(xd.cpu(), g["ddpm_x_prev"])
 
+    # Alignment contract of the stand-alone update kernels (include/edtts.h): float4 accesses only when n_per_batch % 4 == 0 AND
+    # every tensor is 16-byte aligned; anything else takes the scalar path with the same results.  Contiguous tensors that start
+    # 4 bytes into an allocation, and a row length that is not a multiple of 4 (odd rows then start misaligned).
+    def off1(t):
+        buf = torch.empty(t.numel() + 1, dtype=t.dtype, device=DEV)
+        v = buf[1:].view(t.shape)
+        v.copy_(t)
+        assert v.is_contiguous() and v.data_ptr() % 16 == 4
+        return v
+
+    xp, x0 = sch.get_ddim_step(off1(g["x"]), cu(g["t"]), cu(g["t_prev"]), off1(g["eps"]), eta=0.0)
+    assert torch.equal(xp.cpu(), g["ddim_x_prev"]) and torch.equal(x0.cpu(), g["ddim_x0"])
+    xd = sch.ddpm_step(off1(g["x"]), cu(g["t"]), cu(g["eps"]), noise=off1(g["ddpm_noise"]))
+    assert torch.equal(xd.cpu(), g["ddpm_x_prev"])
+    B = g["x"].shape[0]
+    cut = lambda t: t.reshape(B, -1)[:, :397].contiguous()  # noqa: E731  (397 % 4 == 1)
+    xp, x0 = sch.get_ddim_step(cu(cut(g["x"])), cu(g["t"]), cu(g["t_prev"]), cu(cut(g["eps"])), eta=0.0)
+    assert torch.equal(xp.cpu(), cut(g["ddim_x_prev"])) and torch.equal(x0.cpu(), cut(g["ddim_x0"]))
+    xd = sch.ddpm_step(cu(cut(g["x"])), cu(g["t"]), cu(cut(g["eps"])), noise=cu(cut(g["ddpm_noise"])))
+    assert torch.equal(xd.cpu(), cut(g["ddpm_x_prev"]))
+
 
 def test_alpha_bar_table_matches_golden(golden):
     """The one table the hot path reads, built by this host's CPU, equals the reference's (bit-exact)."""
@@ -711,6 +732,53 @@ def test_library_noise_is_shard_invariant():
     assert torch.equal(b, a[1:3])
 
 
+def _empty_shard_worker(rank, world, port, q):
+    import os
+    import torch.distributed as dist
+    from edge_diffusion_tts_amd.parallel import ShardedEdgeInference
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.chdir("/tmp")
+    dist.init_process_group("gloo", rank=rank, world_size=world)  # rehearsal backend: both ranks share this box's one GPU
+    try:
+        cfg = CFG(device=DEV)
+        dec = make_decoder(cfg, 0)
+        infer = EdgeInference(cfg, DiffusionSchedule(cfg.diff_steps).to(DEV), torch.nn.Identity(), dec)
+        sem = torch.randint(0, 512, (1, 32), generator=torch.Generator().manual_seed(4)).to(DEV)  # ONE utterance, two ranks
+        out = ShardedEdgeInference(infer).generate_mel(sem, 4, seed=9)   # library Philox noise: the CUDA branch of the sharded path
+        ref = infer.generate_mel(sem, 4, seed=9)
+        sem3 = torch.randint(0, 512, (3, 32), generator=torch.Generator().manual_seed(5)).to(DEV)  # ragged: 2 + 1
+        out3 = ShardedEdgeInference(infer).generate_mel(sem3, 4, seed=9)
+        q.put((rank, bool(torch.equal(out, ref)) and bool(torch.equal(out3, infer.generate_mel(sem3, 4, seed=9)))))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_sampler_with_fewer_utterances_than_ranks():
+    """ShardedEdgeInference on the GPU path with total < world (BASELINE config 1, B = 1, on 2 ranks): the rank with the empty shard
+    draws nothing (a zero-element tensor has a NULL data pointer: edtts_randn must not be called with it), skips the sampler and
+    joins the gather; every rank receives the single-GPU result.  Two processes share the one GPU of this box, gloo collective."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_empty_shard_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+    res = dict(q.get(timeout=5) for _ in procs)
+    assert all(p.exitcode == 0 for p in procs) and res == {0: True, 1: True}
+    # the entry point itself: n = 0 is a no-op even with a NULL pointer; reserved stream ids are refused
+    from edge_diffusion_tts_amd import native
+    assert native.randn((0, 64, 80), DEV, seed=1).shape == (0, 64, 80)
+    assert native.lib().edtts_randn(None, 0, 1, 0, 0, 1.0, None) == 0
+    with pytest.raises(native.EdttsError, match="reserved"):
+        native.randn((1, 4, 80), DEV, seed=1, stream_id=0x10000)
+
+
 def test_config5_full_size_graph():
     """BASELINE config 5 at full size: 1000-step DDPM sampler, B=64, T=512, captured as ONE hipGraph (5 launches per step) and
     replayed; the replay equals the eager run bitwise and stays finite."""
@@ -804,12 +872,83 @@ def test_bf16_sampler_properties():
         eps = d16(xs, tt, sem, torch.full((B,), i, device=DEV))
         xs, x0 = sch.get_ddim_step(xs, tt, torch.full((B,), max(t - 250, 0), device=DEV), eps)
     assert torch.equal(a, x0)
-    # against the CPU oracle (fp32): bf16 rounding of eps is amplified 64171x at t=999 where x0 is not clamped, so compare the
-    # median and the 99th percentile rather than the maximum
-    ref = O.generate_mel(sd, O.schedule_tables(1000)["alpha_bar"], sem.cpu(), x.cpu(), 4, heads=2)
-    err = (a.cpu().double() - ref.double()).abs().flatten()
-    print(f"bf16 4-step sampler vs fp32 oracle: median {float(err.median()):.2e} p99 {float(err.quantile(0.99)):.2e}")
-    assert float(err.median()) < 5e-3 and float(err.quantile(0.99)) < 0.3
+
+
+def test_bf16_sampler_vs_reference_autocast(golden):
+    """The bar for the bf16 sampler comes from the reference itself: its own generate_mel under torch.autocast("cpu", bfloat16)
+    against its fp32 run on the same weights, tokens and start noise (tests/golden/make_golden_r3.py: bf16_sampler).  bf16
+    rounding of eps is amplified 64171x at t=999 where x0 is not clamped, so the error of ANY bf16 run is a
+    distribution with a heavy tail; ours must be no worse than the reference's own at the median, the 99th percentile and --
+    outside the t=999 band -- the maximum."""
+    g = golden("bf16_sampler")
+    H, L, heads = (int(v) for v in g["cfg"].tolist())
+    cfg = CFG(hidden=H, layers=L, heads=heads, device=DEV)
+    dec = EdgeDiffusionDecoder(cfg, compute_dtype="bf16")
+    dec.load_state_dict(synth_state_dict(cfg, 2))
+    dec = dec.to(DEV).eval()
+    infer = EdgeInference(cfg, DiffusionSchedule(cfg.diff_steps).to(DEV), torch.nn.Identity(), dec)
+    ours = infer.generate_mel(cu(g["sem_idx"]), 4, x_T=cu(g["x_T"])).cpu()
+    ref = g["out_f32"].double()
+    e_ours, e_ref = (ours.double() - ref).abs(), (g["out_autocast"].double() - ref).abs()
+    band = amplification_band(g["x_T"], g["eps0"], k=64.0)  # a bf16 eps error (~1e-2) moves |x0| by up to ~600 before the clamp
+    q = lambda e, p: float(e.flatten().quantile(p))
+    print(f"bf16 4-step sampler vs the reference's fp32 run: ours median {q(e_ours, .5):.2e} p99 {q(e_ours, .99):.2e} max outside the band "
+          f"{float(e_ours[~band].max()):.2e} | reference autocast(bf16): median {q(e_ref, .5):.2e} p99 {q(e_ref, .99):.2e} max outside "
+          f"{float(e_ref[~band].max()):.2e} | in band: {int(band.sum())} of {band.numel()}")
+    assert q(e_ours, .5) <= 1.1 * q(e_ref, .5) and q(e_ours, .99) <= 1.1 * q(e_ref, .99)
+    assert float(e_ours[~band].max()) <= 1.1 * float(e_ref[~band].max())
+    assert float(ours.abs().max()) <= 3.0 and bool(torch.isfinite(ours).all())
+
+
+def _cfg3_bf16():
+    cfg = CFG(hidden=256, layers=8, heads=8, device=DEV)
+    dec = EdgeDiffusionDecoder(cfg, max_len=1024, compute_dtype="bf16")
+    dec.load_state_dict(synth_state_dict(cfg, 1, max_pos=1024))
+    return cfg, dec.to(DEV).eval()
+
+
+def test_bf16_full_size_config3_properties():
+    """BASELINE config 3 at FULL size (hidden 256, L = 8, heads 8, B = 256, T = 1024, bf16: 2 048 blocks per launch, q / k / v^T
+    ping-pong, the block-shared LDS-DMA weight ring, the k_ctx16 image stores): too big for the oracle -> size-independent
+    properties, as for config 2: run twice bitwise equal; slices {0, 131, 255} of the big batch == the same utterances in a small
+    batch (bitwise); finite and clamped."""
+    cfg, dec = _cfg3_bf16()
+    infer = EdgeInference(cfg, DiffusionSchedule(cfg.diff_steps).to(DEV), torch.nn.Identity(), dec)
+    gen = torch.Generator().manual_seed(33)
+    B, S = 256, 512
+    sem = torch.randint(0, 512, (B, S), generator=gen).to(DEV)
+    x = torch.randn(B, 2 * S, 80, generator=gen).to(DEV)
+    big = infer.generate_mel(sem, 4, x_T=x)
+    assert big.shape == (B, 1024, 80) and bool(torch.isfinite(big).all()) and float(big.abs().max()) <= 3.0
+    assert torch.equal(big, infer.generate_mel(sem, 4, x_T=x))
+    idx = [0, 131, 255]
+    small = infer.generate_mel(sem[idx].contiguous(), 4, x_T=x[idx].contiguous())
+    assert torch.equal(small, big[idx])
+    # one utterance against the fp32 INSTANCE of the same decoder (the oracle needs minutes at this size): bf16-level agreement
+    d32 = EdgeDiffusionDecoder(cfg, max_len=1024)
+    d32.load_state_dict(synth_state_dict(cfg, 1, max_pos=1024))
+    d32 = d32.to(DEV).eval()
+    t, si = torch.full((1,), 600, device=DEV), torch.full((1,), 1, device=DEV)
+    e16, e32 = dec(x[131:132].contiguous(), t, sem[131:132].contiguous(), si), d32(x[131:132].contiguous(), t, sem[131:132].contiguous(), si)
+    assert rms(e16.cpu(), e32.cpu()) < BF16_RMS_TOL and max_abs(e16.cpu(), e32.cpu()) < BF16_MAX_TOL
+
+
+def test_bf16_no_cross_block_hazard_when_utterances_straddle_block_rounds():
+    """The bf16 twin of test_no_cross_block_hazard...: T = 768 -> 6 blocks per utterance, B = 64 -> 384 blocks; blocks of one launch
+    run at different times and a block's QKV tail writes the NEXT layer's K / V^T images while later neighbours still read this
+    layer's halo tiles -- hence the two image sets.  Every probed utterance of the batch must equal the same utterance run alone."""
+    cfg, dec = _cfg3_bf16()
+    gen = torch.Generator().manual_seed(22)
+    B, S = 64, 384
+    x = torch.randn(B, 2 * S, 80, generator=gen).to(DEV)
+    sem = torch.randint(0, 512, (B, S), generator=gen).to(DEV)
+    t = torch.full((B,), 600, device=DEV)
+    si = torch.full((B,), 1, device=DEV)
+    big = dec(x, t, sem, si)
+    assert bool(torch.isfinite(big).all())
+    for u in (0, 5, 13, 21, 29, 37, 45, 53, 61, 63):
+        solo = dec(x[u:u + 1].contiguous(), t[:1], sem[u:u + 1].contiguous(), si[:1])
+        assert torch.equal(solo[0], big[u]), u
 
 
 def test_bf16_unsupported_head_dim_raises():
@@ -858,10 +997,39 @@ def test_inpaint_samplers(golden):
     assert torch.equal(a, b) and bool(torch.isfinite(a).all()) and torch.equal(a[:, :ov], k2)
     with pytest.raises(IndexError):
         smp.inpaint_teacher_refine(cu(g["x_coarse"]), feats, None, 0, 1.0, 4)   # t_start = 1000: outside the tables, as in the reference
-    # chunk loop: 3 chunks with a 25 % overlap, cross-faded
-    long_feats = torch.randn(1, 60, cfg.semantic_dim, generator=torch.Generator().manual_seed(1)).to(DEV)
-    mel = smp.generate_long(long_feats, total_frames=112, chunk_frames=48, overlap_frames=12, steps=3, cfg_scale=1.0, seed=4)
-    assert mel.shape == (1, 112, 80) and bool(torch.isfinite(mel).all())
+
+
+@pytest.mark.gpu
+def test_longform_stitch(golden):
+    """inference_pipeline.py:296-367 through InpaintSampler.generate_long: three chunks (the last one ragged) refined with
+    classifier-free guidance, each conditioned on the previous tail, de-normalised with per-chunk statistics, exp, cross-faded in
+    the LINEAR domain and divided by the summed window -- against the reference's own loop statement run on its own closures with
+    the same draws (tests/golden/make_golden_r3.py).  Tolerance 5e-4 of the largest linear-mel value."""
+    from edge_diffusion_tts_amd import InpaintSampler
+    g = golden("longform_stitch")
+    cfg = CFG(device=DEV)
+    dec = make_decoder(cfg, 0)
+    smp = InpaintSampler(cfg, DiffusionSchedule(cfg.diff_steps).to(DEV), dec)
+    n_chunks = g["latent_slices"].shape[0]
+    draws = [{k: cu(g[f"c{c}_{k}"]) for k in ("x_coarse", "noise", "noise_k") if f"c{c}_{k}" in g} for c in range(n_chunks)]
+    stats = [(cu(g[f"c{c}_mean"]), cu(g[f"c{c}_std"])) for c in range(n_chunks)]
+    steps, strength, scale = g["params"].tolist()
+    total, chunk, ov, hop_len, sr = (int(v) for v in g["geometry"].tolist())
+    out = smp.generate_long(cu(g["z_q_global"]), total, chunk, ov, stats, strength=strength, steps=int(steps), cfg_scale=scale,
+                            hop_length=hop_len, sample_rate=sr, draws=draws).cpu()
+    ref = g["final_mel"]
+    assert out.shape == ref.shape == (cfg.n_mels, total)
+    err = max_abs(out, ref)
+    print(f"long-form stitch vs the reference's loop: max-abs {err:.2e} of a {float(ref.abs().max()):.3f} peak")
+    assert err <= 5e-4 * float(ref.abs().max())
+    # library noise path: deterministic per seed, finite, non-negative (a weighted mean of exponentials); no overlap = plain concatenation
+    a = smp.generate_long(cu(g["z_q_global"]), total, chunk, ov, stats, strength=strength, steps=2, hop_length=hop_len, sample_rate=sr, seed=4)
+    b = smp.generate_long(cu(g["z_q_global"]), total, chunk, ov, stats, strength=strength, steps=2, hop_length=hop_len, sample_rate=sr, seed=4)
+    assert torch.equal(a, b) and bool(torch.isfinite(a).all()) and float(a.min()) >= 0.0
+    flat = smp.generate_long(cu(g["z_q_global"]), 96, 48, 0, stats[:2], strength=strength, steps=2, hop_length=hop_len, sample_rate=sr, seed=4)
+    assert flat.shape == (cfg.n_mels, 96) and bool(torch.isfinite(flat).all())
+    with pytest.raises(ValueError):
+        smp.generate_long(cu(g["z_q_global"]), total, chunk, chunk, stats)
 
 
 # ---------------------------------------------------------------------------------------------------------------

@@ -185,3 +185,58 @@ def test_decoder_without_adaln_uses_plain_rmsnorm_keys():
     assert set(native.slot_names(cfg.layers)) <= set(slots)
     assert float(slots["layers.1.norm3.proj.weight"].abs().max()) == 0.0 and slots["layers.1.norm3.proj.bias"].shape == (320,)
     assert torch.equal(slots["layers.2.norm1.norm.weight"], dec.state_dict()["layers.2.norm1.weight"])
+
+
+def test_build_depends_on_every_kernel_source(tmp_path):
+    """build() must rebuild when ANY file under csrc/ or include/ is newer than the library (round 2's list named three of five)."""
+    import __graft_entry__ as G
+    srcs = {os.path.basename(p) for p in G._sources()}
+    assert {"edtts_kernels.hip", "edtts_device.h", "edtts_bf16.h", "edtts_melpost.h", "edtts.h"} <= srcs
+    listed = {f for d in ("edge-diffusion-tts_amd/csrc", "include") for f in os.listdir(os.path.join(REPO, d)) if f.endswith((".hip", ".h"))}
+    assert listed <= srcs
+    if os.path.exists(G.LIB):
+        bf = os.path.join(REPO, "edge-diffusion-tts_amd", "csrc", "edtts_bf16.h")
+        st = os.stat(bf)
+        try:
+            os.utime(bf, (st.st_atime, os.path.getmtime(G.LIB) + 10))
+            assert G._stale()
+        finally:
+            os.utime(bf, (st.st_atime, st.st_mtime))
+
+
+def test_no_product_kernel_uses_scratch():
+    """The compile's -Rpass-analysis=kernel-resource-usage report (kept next to the library by build()): every kernel of the shipped
+    library lives in registers -- a spilling instance is a build error (round 2 shipped one with 76 B/lane)."""
+    import __graft_entry__ as G
+    sample = ("x.hip:1:1: remark: Function Name: _Z3foo [-Rpass-analysis=kernel-resource-usage]\n"
+              "x.hip:1:1: remark:     VGPRs: 256 [-Rpass-analysis=kernel-resource-usage]\n"
+              "x.hip:1:1: remark:     AGPRs: 256 [-Rpass-analysis=kernel-resource-usage]\n"
+              "x.hip:1:1: remark:     ScratchSize [bytes/lane]: 76 [-Rpass-analysis=kernel-resource-usage]\n"
+              "x.hip:1:1: remark:     VGPRs Spill: 18 [-Rpass-analysis=kernel-resource-usage]\n")
+    assert G.kernel_resources(sample) == {"_Z3foo": {"vgpr": 256, "agpr": 256, "scratch": 76, "spill": 18}}
+    with pytest.raises(RuntimeError, match="scratch"):
+        G.check_no_scratch(sample)
+    if not os.path.exists(G.RESOURCE_LOG):
+        pytest.skip("library not built by build() in this checkout")
+    res = G.kernel_resources(open(G.RESOURCE_LOG).read())
+    layer = [k for k in res if "k_layer" in k]
+    assert len(layer) >= 12 and all(v["scratch"] == 0 for v in res.values())
+    # the product library carries no experiment instantiations (two-launch layer halves, stand-alone attention kernels)
+    assert not any("k_attn16" in k for k in res)
+    assert not any(re.search(r"k_layerIN5edtts3CfgI[^E]*EELi\dELi[12]E", k) for k in res), "PART_ATTN / PART_FFN instances in the product build"
+
+
+def test_workspace_cache_evicts_least_recently_used():
+    """decoder.workspace(): bounded cache, least-recently-USED entry dropped first (round 2 cleared the whole cache, which could free
+    a workspace a captured graph still replays into; those are pinned -- GPU test test_samplers_are_graph_capturable)."""
+    cfg = CFG(device="cpu")
+    dec = EdgeDiffusionDecoder(cfg)
+    dec.WORKSPACE_CACHE = 3
+    a = dec.workspace(1, 32, 16, 1, "cpu")
+    b = dec.workspace(2, 32, 16, 1, "cpu")
+    c = dec.workspace(3, 32, 16, 1, "cpu")
+    assert dec.workspace(1, 32, 16, 1, "cpu") is a  # a becomes the most recently used
+    d = dec.workspace(4, 32, 16, 1, "cpu")          # evicts b, the least recently used
+    assert dec.workspace(1, 32, 16, 1, "cpu") is a and dec.workspace(3, 32, 16, 1, "cpu") is c and dec.workspace(4, 32, 16, 1, "cpu") is d
+    assert dec.workspace(2, 32, 16, 1, "cpu") is not b and len(dec._workspaces) == 3
+    assert a.dtype == torch.uint8 and not bool(a.any())
