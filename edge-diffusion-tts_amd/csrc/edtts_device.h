@@ -69,14 +69,20 @@ struct Cfg {
   static constexpr int MT = MEL / 16;             // feature tiles of the mel dim
   static constexpr int R = H / 2, RT = R / 16;    // kv_lora_rank (transformer.py:113) and its tiles
   static constexpr int VR = (HEADS - 1) * DH + DHP;  // rows of a V^T buffer (last head padded)
+  // Waves per block.  The waves of a block never synchronise, so the block size only sets how many waves must FINISH before the
+  // CU's freed SIMDs get new work: two-wave blocks (two resident per CU at H = 160) measured 0.6 % faster than four-wave ones
+  // (B=256, T=512: 0.9455 vs 0.9517 ms per layer launch), one-wave blocks the same as two.  LDS: each wave parks HT*NF KiB.
 #ifndef EDTTS_WMAX
-#define EDTTS_WMAX 4
+#define EDTTS_WMAX 2
 #endif
-  static constexpr int WAVES0 = (HT * NF * 4 <= 160) ? 4 : 2;  // waves per block (each parks its residual tile, HT*NF KiB, in LDS)
-  static constexpr int WAVES = WAVES0 < EDTTS_WMAX ? WAVES0 : EDTTS_WMAX;
+  static constexpr int WAVES0 = (HT * NF * 4 <= 160) ? 4 : 2;
+  // (The 16-frames-per-wave instances keep four-wave blocks = one block per CU: they fit 256 registers, and the dispatcher put the
+  // two waves of a SECOND two-wave block onto the same two SIMDs as the first -- B=32, T=512: 0.225 ms per layer launch against
+  // 0.154 with four-wave or one-wave blocks.  The 32-frame instances need > 256 registers, one wave per SIMD is all that fits.)
+  static constexpr int WAVES = NF == 1 ? WAVES0 : (WAVES0 < EDTTS_WMAX ? WAVES0 : EDTTS_WMAX);
   // the cross-attention q tile goes through LDS when it fits next to the parked residual tiles (160 KiB per block at H = 160,
   // NF = 2), else through this wave's (already consumed) self-attention q rows in global memory
-  static constexpr bool Q_IN_LDS = WAVES * WF * H * 4 * 2 <= 160 * 1024;
+  static constexpr bool Q_IN_LDS = WF * H * 4 * 2 <= 40 * 1024;  // per wave: a quarter of the CU's 160 KiB (four waves per CU, in 1, 2 or 4 blocks)
   static constexpr int THREADS = 64 * WAVES;
   static_assert(NF == 1 || NF == 2 || NF == 4, "frame tiles per wave");
   static_assert(H % 32 == 0 && MEL % 16 == 0 && H % HEADS == 0, "dims");
@@ -94,6 +100,47 @@ EDTTS_DEV f4 ldg4_sbase(const float* base, unsigned byte_off) {
 }
 EDTTS_DEV f2 ldg2_sbase(const float* base, unsigned byte_off) {
   return *reinterpret_cast<const f2*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+
+// LDS-DMA of a register-layout tile: for every (nt, ft) one global_load_lds_dwordx4 moves this lane's float4 at
+// src[16 nt + ft * 16 * ld] to lds_wave[(nt * NF + ft) * 64 + lane] (64 lanes x 16 B land lane-contiguous) without passing through
+// registers.  lds_wave is wave-uniform; src is this lane's pointer (row fq, feature quad g).
+// Written as inline asm ON PURPOSE: with the builtin, hipcc's waitcnt pass cannot count an outstanding LDS-DMA and turns every
+// later wait of the attention loop into s_waitcnt vmcnt(0) (the K / V^T requests of the next step are then waited for at once).
+// Hidden from the pass, the DMAs are just OLDER entries of the in-order vmcnt queue: every counted wait the compiler emits for
+// a later load also covers them (conservatively), so by the first use of ANY load issued after this call the tile has landed --
+// the caller reads it many thousands of cycles later.  (s_nop: one wait state between the SALU write of M0 and the DMA.)
+template <int NT, int NF>
+EDTTS_DEV void dma_tile_to_lds(const float* src, int ld, f4* lds_wave) {
+  typedef __attribute__((address_space(3))) char* lds_char_t;
+  const unsigned base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_char_t)(char*)lds_wave);
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int ft = 0; ft < NF; ++ft) {
+      const float* p = src + 16 * nt + (size_t)ft * 16 * ld;
+      asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(p), "s"(base + (unsigned)(nt * NF + ft) * 1024u) : "m0", "memory");
+    }
+}
+
+// Buffer loads: address = descriptor base (4 SGPRs) + wave-uniform byte offset in an SGPR (soffset) + per-lane byte offset in ONE
+// VGPR that never changes (+ a 12-bit immediate).  All the per-load address arithmetic of a stream is then SALU work -- the
+// global_load forms hipcc picks for "uniform base + lane offset" rebuild a 64-bit lane address with a VALU instruction per load
+// (v_lshl_add_u64: 12 per attention step, ~14 per FFN iteration in the round-2 kernel; VALU time is MFMA time on fp32).
+#ifndef EDTTS_BUFLOAD
+#define EDTTS_BUFLOAD 1
+#endif
+typedef unsigned u4v __attribute__((ext_vector_type(4)));
+typedef unsigned u2v __attribute__((ext_vector_type(2)));
+EDTTS_DEV __amdgpu_buffer_rsrc_t make_rsrc(const void* base) {
+  // raw buffer, stride 0, no range limit (the offsets are the kernel's own tile arithmetic), gfx9 word 3 = DATA_FORMAT 32-bit
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0xFFFFFFFF, 0x00020000);
+}
+EDTTS_DEV f4 bufld4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+EDTTS_DEV f2 bufld2(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(f2, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
 }
 
 // Correctly rounded fp32 sqrt / divide via fp64 (53 >= 2*24+2 bits, so rounding the fp64 result to fp32 is the
@@ -140,19 +187,38 @@ constexpr int kRefillBurst = EDTTS_RB;
 template <int RN>
 struct FragRing {
   static constexpr int RN_ = RN;
+#if EDTTS_BUFLOAD
+  __amdgpu_buffer_rsrc_t rs;  // the kernel's fragment stream
+  unsigned soff;              // byte offset of position 0 of the current phase (wave-uniform: SALU arithmetic)
+  unsigned voff;              // lane * 16
+#else
   const f4* p;  // lane-offset pointer to position 0 of the current phase
+#endif
   f4 r[RN];
+  EDTTS_DEV f4 frag(int i) const {
+#if EDTTS_BUFLOAD
+    return bufld4(rs, voff, soff + (unsigned)i * 1024u);
+#else
+    return p[i * 64];
+#endif
+  }
   EDTTS_DEV void prime(const float* base, int lane) {
+#if EDTTS_BUFLOAD
+    rs = make_rsrc(base);
+    soff = 0;
+    voff = (unsigned)lane * 16u;
+#else
     p = reinterpret_cast<const f4*>(base) + lane;
+#endif
 #pragma unroll
-    for (int i = 0; i < RN; ++i) r[i] = p[i * 64];
+    for (int i = 0; i < RN; ++i) r[i] = frag(i);
   }
   EDTTS_DEV const f4& at(int i) const { return r[i % RN]; }
   // Refill the slots of positions [lo, hi) (all consumed) in ONE burst.  Every interruption of the MFMA stream by VMEM
   // issue costs ~20 cycles plus ~3 per load (scratch/mfma_probe3.cpp), so the loads go out kRefillBurst at a time.
   EDTTS_DEV void refill(int lo, int hi) {
 #pragma unroll
-    for (int i = lo; i < hi; ++i) r[i % RN] = p[(i + RN) * 64];
+    for (int i = lo; i < hi; ++i) r[i % RN] = frag(i + RN);
     __builtin_amdgcn_sched_barrier(0);
   }
   // called after position i of an N-fragment phase has been consumed
@@ -162,7 +228,11 @@ struct FragRing {
     if ((i + 1) % B == 0) refill(i + 1 - B, i + 1);
     else if (i == N - 1) refill(N - N % B, N);
   }
+#if EDTTS_BUFLOAD
+  EDTTS_DEV void advance(int n) { soff += (unsigned)n * 1024u; }
+#else
   EDTTS_DEV void advance(int n) { p += n * 64; }
+#endif
 };
 
 // out^T tile (16 features x 16*NF frames) += sum_kt frag(kt) * in[kt]: one n-major phase of KT fragments.  At NF = 2 even /
@@ -439,16 +509,26 @@ EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, cons
   // 1.5 % faster on the layer kernel than per-load 64-bit address arithmetic on the lanes.
   const unsigned koff = (unsigned)(fq * H + 4 * g) * 4u, koff_rem = (unsigned)(fq * H + 2 * g) * 4u;
   const unsigned voff = (unsigned)(fq * ldv + 4 * g) * 4u, voff_rem = (unsigned)(vrow_rem * ldv + 4 * g) * 4u;
+#if EDTTS_BUFLOAD
+  const __amdgpu_buffer_rsrc_t rsK = make_rsrc(Kb), rsV = make_rsrc(VTb);
+#endif
   auto load_k = [&](const Geo& q, int hd, int c, KVFrag<C>& f) {
     c = c < q.nchunk ? c : q.nchunk - 1;
 #pragma unroll
     for (int t = 0; t < CH; ++t) {
       int kt = q.kt_lo + c * CH + t;
       kt = kt < q.kt_hi ? kt : q.kt_hi - 1;
+#if EDTTS_BUFLOAD
+      const unsigned so = (unsigned)((kt << 4) * H + hd * DH) * 4u;  // uniform byte offset of (key tile, head)
+#pragma unroll
+      for (int a = 0; a < DFULL; ++a) f.ka[t][a] = bufld4(rsK, koff + 64u * a, so);
+      if (DREM) f.kr[t] = bufld2(rsK, koff_rem + 64u * DFULL, so);
+#else
       const float* ku = Kb + (size_t)(kt << 4) * H + hd * DH;  // uniform
 #pragma unroll
       for (int a = 0; a < DFULL; ++a) f.ka[t][a] = ldg4_sbase(ku + 16 * a, koff);
       if (DREM) f.kr[t] = ldg2_sbase(ku + 16 * DFULL, koff_rem);
+#endif
     }
   };
   auto load_v = [&](const Geo& q, int hd, int c, VFrag<C>& f) {
@@ -459,8 +539,13 @@ EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, cons
       kt = kt < q.kt_hi ? kt : q.kt_hi - 1;
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) {
+#if EDTTS_BUFLOAD
+        const unsigned so = (unsigned)((hd * DH + 16 * dt) * ldv + (kt << 4)) * 4u;  // uniform
+        f.v[t][dt] = bufld4(rsV, (DREM && dt == DT - 1) ? voff_rem : voff, so);
+#else
         const float* vu = VTb + (size_t)(hd * DH + 16 * dt) * ldv + (kt << 4);  // uniform
         f.v[t][dt] = ldg4_sbase(vu, (DREM && dt == DT - 1) ? voff_rem : voff);
+#endif
       }
     }
   };

@@ -701,12 +701,23 @@ __global__ __launch_bounds__(C::THREADS) void k_layer(KArgs a) {
 #endif
   // ---- x = x + attn(norm1(x, cond))   (transformer.py:142-146; q/k/v were produced by the previous kernel) ----
   if (PART != PART_FFN) {
+#ifndef EDTTS_H_DMA
+#define EDTTS_H_DMA 0  // measured (B=256, T=512, same device): 0.9293 ms with the DMA vs 0.9281 ms without -- not worth a hidden DMA
+#endif
+#if EDTTS_H_DMA
+    // The residual goes from the h buffer straight to its parking place by LDS-DMA: one global_load_lds_dwordx4 per (nt, ft) lands
+    // lane-contiguous = the register layout of the stash, without passing through registers, and NOTHING waits for it before the
+    // branch is added back at the end of the self-attention (round 2 loaded it into registers, waited, and wrote it to LDS before
+    // the first head's q / K / V^T requests could even be issued: ~3 k cycles of exposed latency per launch, stamps of r03).
+    dma_tile_to_lds<C::HT, NF>(hp, C::H, reinterpret_cast<f4*>(smem) + (size_t)wave * C::HT * NF * 64);
+#else
     // the residual goes from the h buffer straight to its parking place (the loads fly together with the first head's q / K / V^T)
 #pragma unroll
     for (int nt = 0; nt < C::HT; ++nt)
 #pragma unroll
       for (int ft = 0; ft < NF; ++ft) h[nt][ft] = ldg4(hp + 16 * nt + (size_t)ft * 16 * C::H);
     park_h();
+#endif
     // branch tile starts at the projection bias (attention.py:123); the residual itself stays parked until the branch is done
 #pragma unroll
     for (int nt = 0; nt < C::HT; ++nt) {
@@ -1429,9 +1440,17 @@ static unsigned long long* g_stamps_fwd = nullptr;  // diagnostic builds only, s
 #endif
 template <class C>
 struct Launcher {
-  static size_t ring_lds() { return 0; }
+  // One wave of these kernels per SIMD, on EVERY CU: an instance that needs fewer than 257 registers (the 16-frames-per-wave ones
+  // after round 3's register savings: 232) would otherwise be packed two waves per SIMD onto HALF of the CUs by the dispatcher
+  // (measured: B=32, T=512 at 0.232 ms per layer launch instead of 0.155).  Every launch therefore claims a quarter of the CU's
+  // 160 KiB of LDS per wave, whether it uses it or not.
+  static size_t occupancy_lds() { return (size_t)C::WAVES * 40 * 1024; }
+  static size_t ring_lds() { return occupancy_lds(); }
   template <class CC> static size_t stash_lds() { return (size_t)CC::WAVES * CC::HT * CC::NF * 1024; }  // residual parking place
-  static size_t layer_lds() { return stash_lds<C>() + (C::Q_IN_LDS ? (size_t)C::WAVES * C::WF * C::H * sizeof(float) : 0); }
+  static size_t layer_lds() {
+    const size_t need = stash_lds<C>() + (C::Q_IN_LDS ? (size_t)C::WAVES * C::WF * C::H * sizeof(float) : 0);
+    return need > occupancy_lds() ? need : occupancy_lds();
+  }
   // split layer: attention half with this instance (C), FFN + tail half with CF (more frames per wave)
   static constexpr bool SPLIT = (EDTTS_NF_FFN > C::NF) && C::H <= 192;
   using CF = Cfg<C::H, C::HEADS, C::MEL, (SPLIT ? EDTTS_NF_FFN : C::NF)>;
@@ -1440,9 +1459,19 @@ struct Launcher {
   static int ctx_grid(int B, int Sp) { return (B * (Sp / 32) + kCtxWaves - 1) / kCtxWaves; }
   using C2 = Cfg<C::H, C::HEADS, C::MEL, 2>;  // geometry of the context kernel
   // the 16-frames-per-wave instance for small grids (built for the default decoder)
-  static constexpr bool HAS_SMALL = C::NF == 2 && C::H == 160 && !SPLIT;
+  static constexpr bool HAS_SMALL = C::NF == 2 && (C::H == 160 || C::H == 256) && !SPLIT;
   using Small = Cfg<C::H, C::HEADS, C::MEL, 1>;
-  static constexpr int kSmallGridBlocks = 256;  // CUs of an MI355X
+  // one wave of these kernels fills a SIMD (> 256 registers): the device runs 4 * #CUs of them at a time (1024 on an MI355X)
+  static int wave_slots() {
+    static int slots[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 1024;
+    if (!slots[dev]) {
+      int cus = 0;
+      slots[dev] = (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) ? 4 * cus : 1024;
+    }
+    return slots[dev];
+  }
 
   static int ctx(const Layout& lo, const float* blob, const Workspace& ws, float* wsb, int B, int S, const int64_t* sem_idx,
                  const float* sem_feat, hipStream_t st) {
@@ -1482,10 +1511,10 @@ struct Launcher {
                      const float* x, const float* cond_row, int cond_bstride, int tail, float* eps, float* x_prev, float* x0,
                      const float* coef, hipStream_t st, const DdpmStep* ddpm = nullptr, const LmsStep* lms = nullptr,
                      const VpredStepArgs* vp = nullptr) {
-    // Small grids: with 32 frames per wave fewer than one block per CU would be launched (B = 32 at T = 512: 128 blocks on 256
-    // CUs; B = 1: 2 blocks) -- the 16-frames-per-wave instance doubles the number of waves.  Same arithmetic per frame, bitwise.
+    // Small grids: with 32 frames per wave fewer waves than SIMDs would be launched (B = 32 at T = 512: 512 waves for 1024 SIMDs;
+    // B = 1: 8) -- the 16-frames-per-wave instance doubles the number of waves.  Same arithmetic per frame, bitwise.
     if constexpr (HAS_SMALL) {
-      if (2 * grid(B, ws.Tp) <= kSmallGridBlocks)  // ... as long as the doubled grid still runs in one round
+      if (2 * B * (ws.Tp / C::WF) <= wave_slots())  // ... as long as the doubled wave count still runs in one round
         return Launcher<Small>::forward(lo, blob, ws, wsb, B, T, S, window, x, cond_row, cond_bstride, tail, eps, x_prev, x0, coef, st,
                                         ddpm, lms, vp);
     }
@@ -1582,6 +1611,7 @@ struct Launcher {
       if (rc) return rc;
     }
     const int lds = (int)layer_lds();
+    HIP_TRY(hipFuncSetAttribute((const void*)k_prologue<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ring_lds()));
     if constexpr (SPLIT) {
       HIP_TRY(hipFuncSetAttribute((const void*)k_layer<C, TAIL_QKV, PART_ATTN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     } else {

@@ -194,14 +194,28 @@ def test_build_depends_on_every_kernel_source(tmp_path):
     assert {"edtts_kernels.hip", "edtts_device.h", "edtts_bf16.h", "edtts_melpost.h", "edtts.h"} <= srcs
     listed = {f for d in ("edge-diffusion-tts_amd/csrc", "include") for f in os.listdir(os.path.join(REPO, d)) if f.endswith((".hip", ".h"))}
     assert listed <= srcs
-    if os.path.exists(G.LIB):
-        bf = os.path.join(REPO, "edge-diffusion-tts_amd", "csrc", "edtts_bf16.h")
-        st = os.stat(bf)
-        try:
-            os.utime(bf, (st.st_atime, os.path.getmtime(G.LIB) + 10))
-            assert G._stale()
-        finally:
-            os.utime(bf, (st.st_atime, st.st_mtime))
+    # the check is by CONTENT (the snapshot to the GPU box does not keep mtime order): one changed byte in any header -> stale
+    h0 = G._source_hash()
+    real_open = open
+    bf = os.path.join(REPO, "edge-diffusion-tts_amd", "csrc", "edtts_bf16.h")
+
+    class _Patched:
+        def __call__(self, path, mode="r", *a, **k):
+            f = real_open(path, mode, *a, **k)
+            if os.path.abspath(path) == bf and "b" in mode:
+                data = f.read() + b"\n// edit"
+                f.close()
+                import io
+                return io.BytesIO(data)
+            return f
+
+    import builtins
+    builtins.open = _Patched()
+    try:
+        assert G._source_hash() != h0
+    finally:
+        builtins.open = real_open
+    assert G._source_hash() == h0
 
 
 def test_no_product_kernel_uses_scratch():
