@@ -1251,7 +1251,8 @@ __global__ __launch_bounds__(256) void k_ddpm(StepArgs a) {
 // contracts ci = 16 kt + 4 g + r), B = the depthwise tile read from LDS once per wave and kept in registers for all co tiles.
 constexpr int kDsTileT = 64, kDsLd = kDsTileT + 4;
 __global__ __launch_bounds__(256) void k_dsconv_pw(const float* __restrict__ x, const float* __restrict__ dw, const float* __restrict__ pw,
-                                                   const float* __restrict__ pb, int B, int Ci, int Co, int T, int ks, float* __restrict__ z) {
+                                                   const float* __restrict__ pb, int B, int Ci, int Co, int Tin, int T, int ks, int stride,
+                                                   float* __restrict__ z) {  // T = output frames, Tin = input frames
   extern __shared__ float dsm[];  // [Cip][kDsLd]
   const int b = blockIdx.y, t0 = blockIdx.x * kDsTileT, pad = ks / 2;
   const int Cip = (Ci + 15) & ~15;
@@ -1259,10 +1260,10 @@ __global__ __launch_bounds__(256) void k_dsconv_pw(const float* __restrict__ x, 
     const int ci = i / kDsTileT, tl = i % kDsTileT, tt = t0 + tl;
     float acc = 0.f;
     if (ci < Ci && tt < T) {
-      const float* xr = x + ((size_t)b * Ci + ci) * T;
+      const float* xr = x + ((size_t)b * Ci + ci) * Tin;
       for (int j = 0; j < ks; ++j) {
-        const int ts = tt + j - pad;
-        if (ts >= 0 && ts < T) acc = fmaf(xr[ts], dw[ci * ks + j], acc);
+        const int ts = tt * stride + j - pad;  // Conv1d(stride, padding = k/2), layers/conv.py:33-41
+        if (ts >= 0 && ts < Tin) acc = fmaf(xr[ts], dw[ci * ks + j], acc);
       }
     }
     dsm[ci * kDsLd + tl] = acc;
@@ -1362,6 +1363,191 @@ __global__ __launch_bounds__(128) void k_dsconv_norm(const float* __restrict__ z
     }
   } else {
     for (int i = threadIdx.x; i < T; i += 128) yr[i] = f(zr[i]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Fused depthwise-separable conv: ONE block per utterance keeps z = pointwise(depthwise(x)) + bias in REGISTERS between the GEMM
+// and the GroupNorm, so HBM sees exactly the algorithmic traffic (x once in, y once out).  512 threads = 8 waves (two per SIMD, 256
+// registers each: the z tile of C_out = 160, T_out = 512 is 160 of them).  The pointwise weights are staged in LDS once per block
+// ([C_out][C_in + 4]: conflict-free 16-byte reads); a pass covers 128 output frames (wave w owns frames 16 w .. 16 w + 15 of the
+// pass) whose depthwise taps go through a second LDS tile [Cip][128 + 4].  The 1x1 conv runs on v_mfma_f32_16x16x4_f32 with TIME on
+// the MFMA rows (A = depthwise tile, B = weights): the C/D registers of a lane are then 4 CONSECUTIVE frames of one channel = one
+// 16-byte store per (channel tile, pass), and a channel's statistics need two cross-lane adds instead of four.
+// GroupNorm statistics: per-wave per-channel sums -> LDS [8][C_out] -> per channel -> per group, all in fixed order
+// (deterministic), mean first and then the centred sum of squares (two passes over the register tile, as accurate as the
+// reference's GroupNorm).  Shape limits (else edtts_dsconv_forward takes the three-kernel path): C_in <= 16 KT, C_out <= 16 CT,
+// T_out <= 128 NP.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int kDfT = 128, kDfWaves = kDfT / 16, kDfThreads = 64 * kDfWaves;
+constexpr int kDfXld = 264;  // raw input frames per pass and channel: 127 * stride + ksize <= 260 (+ padding against bank conflicts)
+template <int KT, int CT>
+constexpr int dsconv_fused_lds_floats() { return 16 * CT * (16 * KT + 4) + 16 * KT * kDfXld; }
+// erf(x) by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7 absolute, far inside the layer's 1e-5 budget): 1 rcp + 1 exp2 + 7 VALU
+// against ~35 instructions of the library erff -- the GELU of 21 M outputs is 19 us of chip-wide VALU time with the latter.
+EDTTS_DEV float erf_as(float x) {
+  const float ax = fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float e = fast_exp2(ax * ax * -1.4426950408889634f);
+  const float r = fmaf(-p * t, e, 1.0f);
+  return copysignf(r, x);
+}
+template <int KT, int CT, int NP>
+__global__ __launch_bounds__(kDfThreads) void k_dsconv_fused(const float* __restrict__ x, const float* __restrict__ dw, const float* __restrict__ pw,
+                                                             const float* __restrict__ pb, const float* __restrict__ gw, const float* __restrict__ gb,
+                                                             int Ci, int Co, int T, int To, int ks, int stride, int groups, float* __restrict__ y) {
+  extern __shared__ __attribute__((aligned(16))) float dsm_all[];
+  constexpr int Cip = 16 * KT, WLD = Cip + 4;
+  float* wsm = dsm_all;                  // [16 CT][WLD] pointwise weights (rows >= Co and columns >= Ci zero)
+  float* xs = dsm_all + 16 * CT * WLD;   // [Cip][kDfXld] raw input frames of the current pass (zero outside [0, T)); reused for the statistics
+  const int b = blockIdx.x, pad = ks / 2;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fq = lane & 15, g = lane >> 4;
+  const int cpg = Co / groups;
+  const int nin = (kDfT - 1) * stride + ks;  // input frames one pass reads per channel (<= 260, checked by the host)
+  for (int i = threadIdx.x; i < 16 * CT * Cip; i += kDfThreads) {
+    const int co = i / Cip, ci = i % Cip;
+    wsm[co * WLD + ci] = (co < Co && ci < Ci) ? pw[(size_t)co * Ci + ci] : 0.f;
+  }
+  f4 acc[CT][NP];  // lane (fq, g): channel 16 ct + fq, frames 128 p + 16 wave + 4 g + r
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+    for (int p = 0; p < NP; ++p) acc[ct][p] = splat(0.f);
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    const int tb = p * kDfT;
+    if (tb >= To) break;  // (uniform)
+    if (p) __syncthreads();  // the previous pass has been read
+    {  // raw rows of this pass: wave w stages channels w, w + 8, ...; a row is 5 wave-contiguous loads along time, two rows per batch
+      const int t0 = tb * stride - pad;
+      constexpr int SEG = (kDfXld + 63) / 64;
+      for (int c0 = wave; c0 < Cip; c0 += 2 * kDfWaves) {
+        float v[2][SEG];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int ci = c0 + h * kDfWaves;
+          const float* xr = x + ((size_t)b * Ci + (ci < Ci ? ci : 0)) * T;  // (wave-uniform)
+#pragma unroll
+          for (int u = 0; u < SEG; ++u) {
+            const int tl = lane + 64 * u, ts = t0 + tl;
+            v[h][u] = (ci < Ci && tl < nin && ts >= 0 && ts < T) ? xr[ts] : 0.f;
+          }
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int ci = c0 + h * kDfWaves;
+#pragma unroll
+          for (int u = 0; u < SEG; ++u) {
+            const int tl = lane + 64 * u;
+            if (ci < Cip && tl < kDfXld) xs[ci * kDfXld + tl] = v[h][u];
+          }
+        }
+      }
+    }
+    __syncthreads();  // (also covers the weight tile on the first pass)
+    f4 at[KT];  // A operand = depthwise output: rows = this wave's 16 frames (lane fq), k = input channel 16 kt + 4 g + r
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ci = 16 * kt + 4 * g + r;
+        const float* xr = xs + ci * kDfXld + (16 * wave + fq) * stride;
+        const float* wj = dw + (ci < Ci ? ci : 0) * ks;
+        float d = 0.f;
+        for (int j = 0; j < ks; ++j) d = fmaf(xr[j], wj[j], d);  // Conv1d(stride, padding = k/2), layers/conv.py:33-41 (rows >= Ci are zero)
+        at[kt][r] = d;
+      }
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+      if (16 * ct >= Co) break;  // (uniform)
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt) {
+        const f4 w = *reinterpret_cast<const f4*>(wsm + (16 * ct + fq) * WLD + 16 * kt + 4 * g);  // B operand: column = channel 16 ct + fq
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[ct][p] = EDTTS_MFMA(at[kt][r], w[r], acc[ct][p]);
+      }
+    }
+  }
+  // z = acc + bias
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct) {
+    const int co = 16 * ct + fq;
+    const float bias = co < Co ? pb[co] : 0.f;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) acc[ct][p] += bias;
+  }
+  // ---- GroupNorm statistics, deterministic order ----
+  float* wsum = xs;                          // [waves][16 CT]
+  float* chs = xs + kDfWaves * 16 * CT;      // [16 CT] per-channel totals
+  float* gst = chs + 16 * CT;                // [groups][2]: mean, rstd
+  auto channel_reduce = [&](bool centred) {
+    __syncthreads();  // xs / wsum free
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+      const int co = 16 * ct + fq;
+      const float mu = (centred && co < Co) ? gst[2 * (co / cpg)] : 0.f;
+      float s = 0.f;
+#pragma unroll
+      for (int p = 0; p < NP; ++p)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int to = p * kDfT + 16 * wave + 4 * g + r;
+          if (to < To && co < Co) {
+            const float d = acc[ct][p][r] - mu;
+            s += centred ? d * d : d;
+          }
+        }
+      s += __shfl_xor(s, 16, 64);  // over the four lane groups (frames 4 g + r of the wave's 16)
+      s += __shfl_xor(s, 32, 64);
+      if (g == 0) wsum[wave * 16 * CT + co] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < 16 * CT) {
+      float s = 0.f;
+      for (int w = 0; w < kDfWaves; ++w) s += wsum[w * 16 * CT + threadIdx.x];
+      chs[threadIdx.x] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < groups) {
+      float s = 0.f;
+      for (int c = 0; c < cpg; ++c) s += chs[threadIdx.x * cpg + c];
+      const float m = s / (float)(cpg * To);
+      if (centred) gst[2 * threadIdx.x + 1] = rsqrtf(m + 1e-5f);
+      else gst[2 * threadIdx.x] = m;
+    }
+    __syncthreads();
+  };
+  channel_reduce(false);
+  channel_reduce(true);
+  // ---- y = GELU(GroupNorm(z)): 16-byte stores where the row allows it ----
+  const bool vec = (To & 3) == 0;
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct) {
+    const int co = 16 * ct + fq;
+    if (co >= Co) continue;
+    const float mu = gst[2 * (co / cpg)], rs = gst[2 * (co / cpg) + 1], w = gw[co], bb = gb[co];
+    float* yr = y + ((size_t)b * Co + co) * To;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const int t0 = p * kDfT + 16 * wave + 4 * g;
+      f4 o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float v = (acc[ct][p][r] - mu) * rs * w + bb;
+        o[r] = 0.5f * v * (1.0f + erf_as(v * 0.70710678118654752440f));
+      }
+      if (vec && t0 + 3 < To) stg4(yr + t0, o);
+      else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (t0 + r < To) yr[t0 + r] = o[r];
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);  // one channel tile at a time (the z tile leaves no registers for hoisted work)
   }
 }
 
@@ -2212,20 +2398,40 @@ int edtts_ddpm_step(const float* alphas, const float* alpha_bar, const float* be
 }
 
 int edtts_dsconv_forward(const float* x, const float* dw, const float* pw, const float* pb, const float* gn_w, const float* gn_b,
-                         int B, int C_in, int C_out, int T, int ksize, int groups, float* scratch, float* y, void* stream) {
-  if (!x || !dw || !pw || !pb || !gn_w || !gn_b || !scratch || !y) return fail(EDTTS_ERR_ARG, "NULL pointer argument");
-  if (B < 1 || C_in < 1 || C_out < 1 || T < 1 || ksize < 1 || groups < 1 || C_out % groups) return fail(EDTTS_ERR_ARG, "bad sizes");
+                         int B, int C_in, int C_out, int T, int ksize, int stride, int groups, float* scratch, float* y, void* stream) {
+  if (!x || !dw || !pw || !pb || !gn_w || !gn_b || !y) return fail(EDTTS_ERR_ARG, "NULL pointer argument");
+  if (B < 1 || C_in < 1 || C_out < 1 || T < 1 || ksize < 1 || stride < 1 || groups < 1 || C_out % groups) return fail(EDTTS_ERR_ARG, "bad sizes");
   if (C_in > 256) return fail(EDTTS_ERR_UNSUPPORTED, "C_in=%d > 256 (the depthwise tile is kept in registers per wave)", C_in);
+  const int To = (T + 2 * (ksize / 2) - ksize) / stride + 1;  // torch.nn.Conv1d output length
+  if (To < 1) return fail(EDTTS_ERR_ARG, "no output frames (T=%d, kernel %d, stride %d)", T, ksize, stride);
   hipStream_t st = (hipStream_t)stream;
+  // Fused path (z never leaves the registers of one 512-thread block per utterance): the reference's own shape class
+  // (C_in <= 80, C_out <= 160, T_out <= 512) -- HBM traffic = x in + y out.
+  static const bool no_fused = [] { const char* e = getenv("EDTTS_DSCONV_UNFUSED"); return e && e[0] == '1'; }();
+  if (!no_fused && C_in <= 80 && C_out <= 160 && To <= 512 && (kDfT - 1) * stride + ksize <= 260) {
+    static bool attr_done[64] = {};
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    const int lds = dsconv_fused_lds_floats<5, 10>() * (int)sizeof(float);
+    auto kern = k_dsconv_fused<5, 10, 4>;
+    if (dev >= 0 && dev < 64 && !attr_done[dev]) {
+      HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+      attr_done[dev] = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(B), dim3(kDfThreads), lds, st, x, dw, pw, pb, gn_w, gn_b, C_in, C_out, T, To, ksize, stride, groups, y);
+    LAUNCH_CHECK("k_dsconv_fused");
+    return EDTTS_OK;
+  }
+  if (!scratch) return fail(EDTTS_ERR_ARG, "this shape takes the three-kernel path: scratch (B*C_out*T_out + 2*B*groups floats) required");
   float* z = scratch;
-  float* stats = scratch + (size_t)B * C_out * T;
+  float* stats = scratch + (size_t)B * C_out * To;
   const int Cip = (C_in + 15) & ~15;
-  hipLaunchKernelGGL(k_dsconv_pw, dim3((T + kDsTileT - 1) / kDsTileT, B), dim3(256), (size_t)Cip * kDsLd * sizeof(float), st, x, dw, pw, pb,
-                     B, C_in, C_out, T, ksize, z);
+  hipLaunchKernelGGL(k_dsconv_pw, dim3((To + kDsTileT - 1) / kDsTileT, B), dim3(256), (size_t)Cip * kDsLd * sizeof(float), st, x, dw, pw, pb,
+                     B, C_in, C_out, T, To, ksize, stride, z);
   LAUNCH_CHECK("k_dsconv_pw");
-  hipLaunchKernelGGL(k_dsconv_stats, dim3(B * groups), dim3(256), 0, st, z, C_out, T, groups, stats);
+  hipLaunchKernelGGL(k_dsconv_stats, dim3(B * groups), dim3(256), 0, st, z, C_out, To, groups, stats);
   LAUNCH_CHECK("k_dsconv_stats");
-  hipLaunchKernelGGL(k_dsconv_norm, dim3((unsigned)((size_t)B * C_out)), dim3(128), 0, st, z, stats, gn_w, gn_b, C_out, T, groups, y);
+  hipLaunchKernelGGL(k_dsconv_norm, dim3((unsigned)((size_t)B * C_out)), dim3(128), 0, st, z, stats, gn_w, gn_b, C_out, To, groups, y);
   LAUNCH_CHECK("k_dsconv_norm");
   return EDTTS_OK;
 }

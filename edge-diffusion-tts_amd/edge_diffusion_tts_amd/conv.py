@@ -1,9 +1,9 @@
 """DepthwiseSeparableConv -- the exported conv layer of the reference (layers/conv.py:10-64) on MI355X.
 
 Named by the north star but never instantiated by the reference decoder, so it is a standalone op:
-depthwise Conv1d(k, pad k//2, groups=C, no bias) -> pointwise Conv1d(1x1, bias) -> GroupNorm(min(8, C_out)) -> erf-GELU,
-channel-first [B, C, T].  State-dict keys match the reference: depthwise.weight [C,1,k], pointwise.weight [Co,C,1],
-pointwise.bias, norm.weight, norm.bias.  stride must be 1 (the only value the reference's callers could use).
+depthwise Conv1d(k, stride, pad k//2, groups=C, no bias) -> pointwise Conv1d(1x1, bias) -> GroupNorm(min(8, C_out)) -> erf-GELU,
+channel-first [B, C, T] -> [B, C_out, (T + 2*(k//2) - k)//stride + 1].  State-dict keys match the reference: depthwise.weight
+[C,1,k], pointwise.weight [Co,C,1], pointwise.bias, norm.weight, norm.bias.
 """
 from __future__ import annotations
 
@@ -22,9 +22,9 @@ class _Leaf(nn.Module):
 class DepthwiseSeparableConv(nn.Module):
     def __init__(self, in_ch: int, out_ch: int, kernel_size: int = 3, stride: int = 1):
         super().__init__()
-        if stride != 1:
-            raise NotImplementedError("stride != 1 is not built for the MI355X path")
-        self.in_ch, self.out_ch, self.kernel_size = in_ch, out_ch, kernel_size
+        if stride < 1:
+            raise ValueError("stride must be >= 1")
+        self.in_ch, self.out_ch, self.kernel_size, self.stride = in_ch, out_ch, kernel_size, int(stride)
         self.groups = min(8, out_ch)
         self.depthwise, self.pointwise, self.norm = _Leaf(), _Leaf(), _Leaf()
         bd = 1.0 / math.sqrt(kernel_size)
@@ -39,4 +39,4 @@ class DepthwiseSeparableConv(nn.Module):
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         return native.dsconv_forward(x.contiguous(), self.depthwise.weight.reshape(self.in_ch, self.kernel_size).contiguous(),
                                      self.pointwise.weight.reshape(self.out_ch, self.in_ch).contiguous(), self.pointwise.bias,
-                                     self.norm.weight, self.norm.bias, self.groups)
+                                     self.norm.weight, self.norm.bias, self.groups, self.stride)

@@ -77,7 +77,7 @@ def lib() -> C.CDLL:
                                        vp, C.c_uint64, f32, vp, vp]
     L.edtts_sample_multistep.argtypes = [C.POINTER(EdttsDims), vp, vp, i32, i32, i32, vp, vp, vp, i32, C.POINTER(C.c_int64),
                                          C.POINTER(f32), vp, vp, vp, vp]
-    L.edtts_dsconv_forward.argtypes = [vp] * 6 + [i32] * 6 + [vp, vp, vp]
+    L.edtts_dsconv_forward.argtypes = [vp] * 6 + [i32] * 7 + [vp, vp, vp]
     L.edtts_profile_enable.argtypes = [i32]
     L.edtts_profile_collect.argtypes = [C.POINTER(C.c_double), C.POINTER(i32)]  # arrays of 2
     for name in EXPORTED_SYMBOLS:
@@ -229,15 +229,18 @@ def ddpm_step(alphas, alpha_bar, betas, post_var, x_t, t, eps, noise) -> torch.T
     return out
 
 
-def dsconv_forward(x, dw, pw, pb, gn_w, gn_b, groups: int) -> torch.Tensor:
+def dsconv_forward(x, dw, pw, pb, gn_w, gn_b, groups: int, stride: int = 1) -> torch.Tensor:
     B, Ci, T = x.shape
     Co, ks = pw.shape[0], dw.shape[-1]
-    y = torch.empty(B, Co, T, device=x.device, dtype=torch.float32)
-    scratch = torch.empty(B * Co * T + 2 * B * groups, device=x.device, dtype=torch.float32)
+    To = (T + 2 * (ks // 2) - ks) // stride + 1
+    if To < 1:
+        raise EdttsError(f"dsconv: no output frames for T={T}, kernel_size={ks}, stride={stride}")
+    y = torch.empty(B, Co, To, device=x.device, dtype=torch.float32)
+    scratch = torch.empty(B * Co * To + 2 * B * groups, device=x.device, dtype=torch.float32)
     f = torch.float32
     lib().edtts_dsconv_forward(_dev_ptr(x, f, "x"), _dev_ptr(dw, f, "depthwise.weight"), _dev_ptr(pw, f, "pointwise.weight"),
                                _dev_ptr(pb, f, "pointwise.bias"), _dev_ptr(gn_w, f, "norm.weight"), _dev_ptr(gn_b, f, "norm.bias"),
-                               B, Ci, Co, T, ks, groups, scratch.data_ptr(), y.data_ptr(), _stream(x.device))
+                               B, Ci, Co, T, ks, int(stride), groups, scratch.data_ptr(), y.data_ptr(), _stream(x.device))
     return y
 
 

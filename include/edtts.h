@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define EDTTS_VERSION 200 /* 0.2.0 */
+#define EDTTS_VERSION 300 /* 0.3.0: edtts_dsconv_forward takes a stride; Philox stream-id domains */
 
 enum {
   EDTTS_OK = 0,
@@ -212,11 +212,14 @@ int edtts_sample_inpaint(const EdttsDims* dims, const void* packed, void* worksp
 
 /* ---- depthwise-separable Conv1d  (layers/conv.py:25-64, DepthwiseSeparableConv.forward) -----------------
  * Standalone exported layer (named by the north star; the decoder never calls it).
- * x [B,C_in,T] channel-first; dw [C_in,k] depthwise taps (stride 1, zero pad k/2, no bias); pw [C_out,C_in],
- * pb [C_out]; GroupNorm(groups, eps 1e-5, affine gn_w/gn_b [C_out]) then exact (erf) GELU -> y [B,C_out,T].
- * scratch: at least B*C_out*T + 2*B*groups floats. */
+ * x [B,C_in,T] channel-first; dw [C_in,k] depthwise taps (Conv1d(k, stride, padding = k/2, groups = C_in, no bias),
+ * conv.py:33-41: T_out = (T + 2*(k/2) - k) / stride + 1); pw [C_out,C_in], pb [C_out]; GroupNorm(groups, eps 1e-5, affine
+ * gn_w/gn_b [C_out]) then exact (erf) GELU -> y [B,C_out,T_out].
+ * C_in <= 80, C_out <= 160, T_out <= 512 (the reference's shape class) run as ONE kernel whose intermediate never leaves
+ * registers (scratch may be NULL); other shapes take a three-kernel path and need scratch of at least
+ * B*C_out*T_out + 2*B*groups floats. */
 int edtts_dsconv_forward(const float* x, const float* dw, const float* pw, const float* pb, const float* gn_w,
-                         const float* gn_b, int B, int C_in, int C_out, int T, int ksize, int groups,
+                         const float* gn_b, int B, int C_in, int C_out, int T, int ksize, int stride, int groups,
                          float* scratch, float* y, void* stream);
 
 /* ---- mel post-processing  (the step after the sampler in the reference's scripts: generate_sample.py:115-145,

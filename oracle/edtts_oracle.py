@@ -346,16 +346,19 @@ def sample_ddpm(sd: SD, tabs: Dict[str, Tensor], sem_idx: Tensor, x_T: Tensor, n
 # ------------------------------------------------------------------------------------------------
 # standalone exported layer named by north_star (not called by the decoder)
 # ------------------------------------------------------------------------------------------------
-def dsconv_forward(x: Tensor, dw: Tensor, pw: Tensor, pb: Tensor, gn_w: Tensor, gn_b: Tensor, groups: int, eps: float = 1e-5) -> Tensor:
-    """layers/conv.py:52-64 -- depthwise k-tap conv (zero pad k//2, no bias) -> pointwise 1x1 (+bias) ->
+def dsconv_forward(x: Tensor, dw: Tensor, pw: Tensor, pb: Tensor, gn_w: Tensor, gn_b: Tensor, groups: int, eps: float = 1e-5,
+                   stride: int = 1) -> Tensor:
+    """layers/conv.py:52-64 -- depthwise k-tap conv (stride, zero pad k//2, no bias; conv.py:33-41) -> pointwise 1x1 (+bias) ->
     GroupNorm(groups) -> exact GELU.  x: [B, C_in, T]; dw: [C_in, 1, k]; pw: [C_out, C_in, 1]."""
     B, C, T = x.shape
     ksz = dw.shape[-1]
     pad = ksz // 2
+    To = (T + 2 * pad - ksz) // stride + 1
     xp = torch.nn.functional.pad(x, (pad, pad))
-    y = torch.zeros_like(x)
+    y = torch.zeros(B, C, To, dtype=x.dtype)
     for j in range(ksz):
-        y = y + xp[:, :, j:j + T] * dw[:, 0, j][None, :, None]
+        y = y + xp[:, :, j:j + (To - 1) * stride + 1:stride] * dw[:, 0, j][None, :, None]
+    T = To
     z = torch.einsum("oc,bct->bot", pw[:, :, 0], y) + pb[None, :, None]
     Co = z.shape[1]
     zg = z.reshape(B, groups, (Co // groups) * T)

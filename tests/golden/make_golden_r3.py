@@ -12,6 +12,7 @@ Fixtures (inputs + the reference's outputs; no reference source is stored):
                     deterministic positive function of the chunk, `z_q_global` (HuBERT features) is synthetic.  Every torch.randn /
                     randn_like draw of the run and the per-chunk (mean, std) the loop derives are recorded, so that the build's
                     generate_long can be driven with exactly the same numbers.
+  dsconv_stride     DepthwiseSeparableConv(stride = 2, 3) (layers/conv.py:25-64), and shapes outside the fused kernel's class
   bf16_sampler      the reference's own generate_mel under torch.autocast("cpu", bfloat16) next to its fp32 run (4-step DDIM, hidden
                     64 / 2 heads of 32 / 2 layers, the smallest bf16-capable shape): the error distribution a bf16 implementation of
                     this sampler has by the reference's own standard.
@@ -185,7 +186,26 @@ def bf16_sampler():
                         out_autocast=npf(outs["bf16"]), eps0=npf(eps0), cfg=np.array([64, 2, 2]))
 
 
-FIXTURES = {"longform_stitch": longform_stitch, "bf16_sampler": bf16_sampler}
+@torch.no_grad()
+def dsconv_stride():
+    """DepthwiseSeparableConv with stride > 1 (layers/conv.py:33-41), plus one case outside the fused kernel's shape class."""
+    from make_golden import RefDSConv
+    d = {}
+    for tag, (ci, co, T_, ks, st) in {"s2": (80, 160, 64, 3, 2), "s3": (24, 40, 37, 5, 3), "wide": (96, 176, 50, 3, 2), "long": (16, 32, 700, 3, 1)}.items():
+        m = RefDSConv(ci, co, kernel_size=ks, stride=st).eval()
+        m.depthwise.weight.copy_(rnd(tuple(m.depthwise.weight.shape), 19, 0, 0.6))
+        m.pointwise.weight.copy_(rnd(tuple(m.pointwise.weight.shape), 19, 1, 0.2))
+        m.pointwise.bias.copy_(rnd(tuple(m.pointwise.bias.shape), 19, 2, 0.1))
+        m.norm.weight.copy_(1.0 + rnd(tuple(m.norm.weight.shape), 19, 3, 0.2))
+        m.norm.bias.copy_(rnd(tuple(m.norm.bias.shape), 19, 4, 0.1))
+        xin = rnd((2, ci, T_), 19, 5, 1.0)
+        d.update({f"{tag}_x": npf(xin), f"{tag}_y": npf(m(xin)), f"{tag}_dw": npf(m.depthwise.weight), f"{tag}_pw": npf(m.pointwise.weight),
+                  f"{tag}_pb": npf(m.pointwise.bias), f"{tag}_gw": npf(m.norm.weight), f"{tag}_gb": npf(m.norm.bias),
+                  f"{tag}_groups": np.array(m.norm.num_groups), f"{tag}_stride": np.array(st)})
+    np.savez_compressed(os.path.join(OUT, "dsconv_stride.npz"), **d)
+
+
+FIXTURES = {"longform_stitch": longform_stitch, "bf16_sampler": bf16_sampler, "dsconv_stride": dsconv_stride}
 
 
 if __name__ == "__main__":

@@ -326,6 +326,46 @@ def test_dsconv(golden):
         assert max_abs(y, g[f"{tag}_y"]) < 1e-5
 
 
+def test_dsconv_stride_and_both_paths(golden, monkeypatch):
+    """stride 2 / 3 (layers/conv.py:33-41: T_out = (T + 2*(k//2) - k)//stride + 1) against reference goldens; the reference's shape
+    class runs the fused one-kernel path (intermediate in registers), "wide" / "long" exceed it and take the three-kernel path;
+    EDTTS_DSCONV_UNFUSED forces that path for the small shapes too -- both must meet the same tolerance."""
+    g, g1 = golden("dsconv_stride"), golden("dsconv")
+
+    def run(gg, tag, stride):
+        ci, co, ks = gg[f"{tag}_x"].shape[1], gg[f"{tag}_pw"].shape[0], gg[f"{tag}_dw"].shape[-1]
+        m = DepthwiseSeparableConv(ci, co, kernel_size=ks, stride=stride)
+        m.load_state_dict({"depthwise.weight": gg[f"{tag}_dw"], "pointwise.weight": gg[f"{tag}_pw"], "pointwise.bias": gg[f"{tag}_pb"],
+                           "norm.weight": gg[f"{tag}_gw"], "norm.bias": gg[f"{tag}_gb"]})
+        y = m.to(DEV)(cu(gg[f"{tag}_x"])).cpu()
+        assert y.shape == gg[f"{tag}_y"].shape, tag
+        return max_abs(y, gg[f"{tag}_y"])
+
+    for tag in ("s2", "s3", "wide", "long"):
+        assert run(g, tag, int(g[f"{tag}_stride"])) < 1e-5, tag
+    # the same small shapes through the three-kernel path (a separate process: the switch is read once per process)
+    import subprocess, sys, os
+    code = ("import sys; sys.path[:0] = %r; import torch, numpy as np\n"
+            "from edge_diffusion_tts_amd import DepthwiseSeparableConv\n"
+            "z = np.load(%r)\n"
+            "for tag in ('s2', 's3'):\n"
+            "    g = {k: torch.from_numpy(z[k]) for k in z.files if k.startswith(tag + '_')}\n"
+            "    m = DepthwiseSeparableConv(g[tag + '_x'].shape[1], g[tag + '_pw'].shape[0], kernel_size=g[tag + '_dw'].shape[-1], stride=int(g[tag + '_stride']))\n"
+            "    m.load_state_dict({'depthwise.weight': g[tag + '_dw'], 'pointwise.weight': g[tag + '_pw'], 'pointwise.bias': g[tag + '_pb'], 'norm.weight': g[tag + '_gw'], 'norm.bias': g[tag + '_gb']})\n"
+            "    y = m.cuda()(g[tag + '_x'].cuda()).cpu()\n"
+            "    assert float((y - g[tag + '_y']).abs().max()) < 1e-5, tag\n"
+            "print('unfused ok')\n") % (sys.path[:3], os.path.join(os.path.dirname(__file__), "golden", "dsconv_stride.npz"))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, EDTTS_DSCONV_UNFUSED="1"), capture_output=True, text=True, timeout=300, cwd="/tmp")
+    assert r.returncode == 0 and "unfused ok" in r.stdout, r.stderr[-1500:]
+    # stride 1 goldens of round 1 through the fused path (test_dsconv) and the benchmark shape: deterministic, finite
+    x = torch.randn(8, 80, 512, generator=torch.Generator().manual_seed(3)).to(DEV)
+    m = DepthwiseSeparableConv(80, 160).to(DEV)
+    a, b = m(x), m(x)
+    assert a.shape == (8, 160, 512) and torch.equal(a, b) and bool(torch.isfinite(a).all())
+    ref = O.dsconv_forward(x.cpu(), m.depthwise.weight.cpu(), m.pointwise.weight.cpu(), m.pointwise.bias.cpu(), m.norm.weight.cpu(), m.norm.bias.cpu(), m.groups)
+    assert max_abs(a.cpu(), ref) < 2e-5
+
+
 def test_forward_large_score_range():
     """Forces the deferred-max rescale branch of the attention kernels (taken when a later key chunk exceeds the softmax
     reference point by > 2^32): q/k projections scaled so that score ranges span hundreds of octaves, plus a spiked context
