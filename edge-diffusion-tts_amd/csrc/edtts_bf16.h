@@ -36,11 +36,11 @@ typedef float f2v __attribute__((ext_vector_type(2)));
 #ifndef EDTTS_STAMP_THREAD
 #define EDTTS_STAMP_THREAD 0   // first lane of the stamped wave of block 0 (192: wave 3 = frames 96..127, an interior tile)
 #endif
-#undef STAMPX  // (edtts_device.h's form stamps EDTTS_STAMP_BLOCK; the bf16 diagnostics were taken on block 0)
 #define STAMP16(i) do { if (a.stamps && blockIdx.x == 0 && threadIdx.x == EDTTS_STAMP_THREAD) a.stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
-#define STAMPX(p, i) do { if ((p) && blockIdx.x == 0 && threadIdx.x == EDTTS_STAMP_THREAD) (p)[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#define STAMPX16(p, i) do { if ((p) && blockIdx.x == 0 && threadIdx.x == EDTTS_STAMP_THREAD) (p)[i] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define STAMP16(i) do { } while (0)
+#define STAMPX16(p, i) do { } while (0)
 #endif
 
 namespace edtts16 {
@@ -411,7 +411,7 @@ EDTTS_DEV void attention16(QF&& qf, const __bf16* __restrict__ Kb, const __bf16*
         nm[h][ft] = 0.f;
       }
     auto step = [&](bool first, int c, int cnext2, bf8 (&KA)[HP][2], bf8 (&VA)[HP][2]) {
-      if (hd == EDTTS_STAMP_HEAD) STAMPX(stamps, sidx++);
+      if (hd == EDTTS_STAMP_HEAD) STAMPX16(stamps, sidx++);
       f4 S[HP][2][NF];
       const bool dummy = c < 0;  // (EDTTS16_EVEN_STEPS: the padding step of an odd step count: every position masked)
       if (dummy) c = nchunk - 1;
@@ -449,7 +449,7 @@ EDTTS_DEV void attention16(QF&& qf, const __bf16* __restrict__ Kb, const __bf16*
       }
 #pragma unroll
       for (int h = 0; h < HP; ++h) load_k(hd + h, cnext2, KA[h]);  // (re-reads a valid tile past the last step)
-      if (hd == EDTTS_STAMP_HEAD) STAMPX(stamps, sidx++);
+      if (hd == EDTTS_STAMP_HEAD) STAMPX16(stamps, sidx++);
       f4 P[HP][2][NF], ps[HP][NF];
       auto exp_and_sum = [&](int h, int ft, float m) {
 #pragma unroll
@@ -529,7 +529,7 @@ EDTTS_DEV void attention16(QF&& qf, const __bf16* __restrict__ Kb, const __bf16*
           lvec[h][ft] += ps[h][ft];
           pb[h][ft] = pack8(P[h][0][ft], P[h][1][ft]);
         }
-      if (hd == EDTTS_STAMP_HEAD) STAMPX(stamps, sidx++);
+      if (hd == EDTTS_STAMP_HEAD) STAMPX16(stamps, sidx++);
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -538,7 +538,7 @@ EDTTS_DEV void attention16(QF&& qf, const __bf16* __restrict__ Kb, const __bf16*
           for (int h = 0; h < HP; ++h) O[h][dt][ft] = EDTTS_MFMA16(VA[h][dt], pb[h][ft], O[h][dt][ft]);
 #pragma unroll
       for (int h = 0; h < HP; ++h) load_v(hd + h, cnext2, VA[h]);
-      if (hd == EDTTS_STAMP_HEAD) STAMPX(stamps, sidx++);
+      if (hd == EDTTS_STAMP_HEAD) STAMPX16(stamps, sidx++);
     };
     // Always two steps per loop iteration, so that no branch surrounds a tile request and hipcc's waitcnt pass counts the
     // outstanding loads exactly (behind a conditional step it waited for tiles that had only just been requested); a step past the
@@ -605,7 +605,7 @@ EDTTS_DEV void attention16(QF&& qf, const __bf16* __restrict__ Kb, const __bf16*
       nm[ft] = 0.f;
     }
     auto step = [&](bool first, int c, int cnext2, bf8 (&KA)[2], bf8 (&VA)[2]) {
-      if (hd == EDTTS_STAMP_HEAD) STAMPX(stamps, sidx++);
+      if (hd == EDTTS_STAMP_HEAD) STAMPX16(stamps, sidx++);
       f4 S[2][NF];
       if (chunk_is_interior(c)) {
         // the reference tile rides in as the C operand itself (written as S = NM; S = mfma(.., S) it cost 16 accumulator moves
@@ -622,7 +622,7 @@ EDTTS_DEV void attention16(QF&& qf, const __bf16* __restrict__ Kb, const __bf16*
           for (int ft = 0; ft < NF; ++ft) S[t][ft] = EDTTS_MFMA16(KA[t], q[ft], S[t][ft]);
       }
       load_k(hd, cnext2, KA);  // (re-reads a valid tile past the last step)
-      if (hd == EDTTS_STAMP_HEAD) STAMPX(stamps, sidx++);
+      if (hd == EDTTS_STAMP_HEAD) STAMPX16(stamps, sidx++);
       f4 P[2][NF], ps[NF];
       auto lane_max = [&](int ft) {
         f4 mv = S[0][ft];
@@ -691,13 +691,13 @@ EDTTS_DEV void attention16(QF&& qf, const __bf16* __restrict__ Kb, const __bf16*
         lvec[ft] += ps[ft];
         pb[ft] = pack8(P[0][ft], P[1][ft]);
       }
-      if (hd == EDTTS_STAMP_HEAD) STAMPX(stamps, sidx++);
+      if (hd == EDTTS_STAMP_HEAD) STAMPX16(stamps, sidx++);
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
         for (int ft = 0; ft < NF; ++ft) O[dt][ft] = EDTTS_MFMA16(VA[dt], pb[ft], O[dt][ft]);
       load_v(hd, cnext2, VA);
-      if (hd == EDTTS_STAMP_HEAD) STAMPX(stamps, sidx++);
+      if (hd == EDTTS_STAMP_HEAD) STAMPX16(stamps, sidx++);
     };
     // (Measured alternatives, same device: groups of KD unconditional steps + a load-free tail so that hipcc's waitcnt pass sees
     // the same number of outstanding loads on every path -- KD=2: 50.1 ms, KD=4: 46.2 ms against 45.7 ms for this loop; fully

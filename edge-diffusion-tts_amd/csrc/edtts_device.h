@@ -32,19 +32,13 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 #define EDTTS_DEV __device__ __forceinline__
 
 // Diagnostic builds (-DEDTTS_EXPERIMENTS -DEDTTS_STAMPS; scratch/stamps_f32.py, stamps_bf16.py): s_memtime stamps of ONE wave.
+// Which one is chosen at run time (environment of the stamps build: EDTTS_STAMP_BLOCK / EDTTS_STAMP_WAVE / EDTTS_STAMP_HEAD ->
+// KArgs::diag_skip = head | wave << 8 | block << 16; defaults: block 8 = logical block 1 after the XCD remap, wave 0, head 1).
 #ifdef EDTTS_STAMPS
-#ifndef EDTTS_STAMP_BLOCK
-#define EDTTS_STAMP_BLOCK 8    // blockIdx.x of the stamped block (8 = logical block 1 after the XCD remap: an interior tile)
-#endif
-#ifndef EDTTS_STAMP_THREAD
-#define EDTTS_STAMP_THREAD 0   // first lane of the stamped wave
-#endif
-#ifndef EDTTS_STAMP_HEAD
-#define EDTTS_STAMP_HEAD 1     // head whose attention steps carry the fine-grained stamps
-#endif
-#define STAMPX(p, i) do { if ((p) && blockIdx.x == EDTTS_STAMP_BLOCK && threadIdx.x == EDTTS_STAMP_THREAD) (p)[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#define STAMP_SEL_HEAD(sel) ((sel) & 0xff)
+#define STAMPX(p, i, sel) do { if ((p) && (int)blockIdx.x == ((sel) >> 16) && (int)threadIdx.x == 64 * (((sel) >> 8) & 0xff)) (p)[i] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
-#define STAMPX(p, i) do { } while (0)
+#define STAMPX(p, i, sel) do { } while (0)
 #endif
 
 namespace edtts {
@@ -439,14 +433,14 @@ struct VFrag {  // V^T fragments (MFMA A operand of P V) of one chunk of key til
 // tiles then feed the k-major projection weights from the fragment ring in one NF-wide phase.
 //   SELF : keys are frames of the same utterance, band |i-j| <= window (layers/attention.py:27-30,108-112)
 //   !SELF: keys are the S context tokens, no mask (layers/mla.py:158-179)
-// qload.q4(row16, col) / q2(...) return q[m0 + 16*row16 + fq][col...] for this lane.
+// qload.q4(row16, col) / q2(row16, col) return q[m0 + 16*row16 + fq][col + 4 g ...] / [col + 2 g ...] for this lane (col wave-uniform).
 // ---------------------------------------------------------------------------------------------------------
 template <class C, bool SELF, class QLoad>
 EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, const float* __restrict__ VTb, int ldv,
                                int nkeys, int window, int m0w, int lane, WStream<C>& ring, f4 (&h)[C::HT][C::NF],
-                               unsigned long long* stamps = nullptr) {
-  int sidx = 0;  // (EDTTS_STAMPS diagnostic builds: four stamps per step of head EDTTS_STAMP_HEAD)
-  (void)sidx; (void)stamps;
+                               unsigned long long* stamps = nullptr, int stamp_sel = 0) {
+  int sidx = 0;  // (EDTTS_STAMPS diagnostic builds: four stamps per step of the selected head)
+  (void)sidx; (void)stamps; (void)stamp_sel;
   constexpr int DH = C::DH, DFULL = C::DFULL, DREM = C::DREM, DT = C::DT, H = C::H, CH = kChunk, NF = C::NF;
   constexpr int NHALF = C::NHALF;
   constexpr int QT = C::QT;  // query tiles per half: 2 (32 frames), or 1 in the small-batch instance (NF = 1)
@@ -461,10 +455,12 @@ EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, cons
   struct Geo {
     int m0, kt_lo, kt_hi, nchunk, klim;
     int cdiag;  // chunk that holds the keys of this half's own frames (self-attention; 0 otherwise)
+    unsigned interior;  // bit c: chunk c (of the first 32 = 1024 keys) is interior (see chunk_is_interior) -- evaluated once per wave, one SALU bit test per step
     int lo_d[QT], span[QT];  // per-lane band limits on d = key - query: valid <=> (unsigned)(d - lo_d) <= span
   };
   auto make_geo = [&](int half) {
     Geo q;
+    q.interior = 0u;
     q.m0 = m0w + 16 * QT * half;
     // The chunk partition and order are those of the enclosing 32-frame pair of query tiles also when a pass covers ONE tile
     // (small-batch instance, QT = 1): a query row then meets exactly the chunk sequence it meets in the 32-frame instances, and
@@ -584,7 +580,8 @@ EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, cons
                 const f2 (&qr)[QT], f4 (&S)[CH][QT], const f4 (&NM)[QT], const float (&nm)[QT]) {
     static_assert(DFULL >= 1, "head_dim >= 16 expected");
     constexpr bool FOLD = decltype(fold_tag)::value;
-    if (chunk_is_interior(q, c)) {
+    const int cc = c < q.nchunk ? c : q.nchunk - 1;
+    if (cc < 32 && ((q.interior >> cc) & 1u)) {  // (chunks past 31 -- beyond the reference's length limits -- take the always-correct masked path)
 #pragma unroll
       for (int t = 0; t < CH; ++t)
 #pragma unroll
@@ -620,7 +617,12 @@ EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, cons
 
   Geo geo[NHALF];
 #pragma unroll
-  for (int hf = 0; hf < NHALF; ++hf) geo[hf] = make_geo(hf);
+  for (int hf = 0; hf < NHALF; ++hf) {
+    geo[hf] = make_geo(hf);
+    unsigned im = 0;
+    for (int c = 0; c < geo[hf].nchunk && c < 32; ++c) im |= (chunk_is_interior(geo[hf], c) ? 1u : 0u) << c;
+    geo[hf].interior = __builtin_amdgcn_readfirstlane(im);
+  }
 
   // q fragments (B operand: lane (fq,g) holds q[query][hd*DH + 16a + 4g + b]) and the K / V^T fragments of the first
   // chunks of a (head, half).  For half 0 they are fetched while the PREVIOUS head's projection phases run, so no head
@@ -637,13 +639,16 @@ EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, cons
   auto chunk_at = [&](const Geo& q, int st) {
     return st >= q.nchunk ? q.nchunk - 1 : (st == 0 ? q.cdiag : (st <= q.cdiag ? st - 1 : st));
   };
-  auto prefetch = [&](const Geo& q, int hd, int half) {
+  auto load_q = [&](int hd, int half) {
 #pragma unroll
     for (int ft = 0; ft < QT; ++ft) {
 #pragma unroll
-      for (int a = 0; a < DFULL; ++a) qa_n[ft][a] = qload.q4(QT * half + ft, hd * DH + 16 * a + 4 * g);
-      if (DREM) qr_n[ft] = qload.q2(QT * half + ft, hd * DH + 16 * DFULL + 2 * g);
+      for (int a = 0; a < DFULL; ++a) qa_n[ft][a] = qload.q4(QT * half + ft, hd * DH + 16 * a);  // (+ 4 g: the lane's quad, in the loader)
+      if (DREM) qr_n[ft] = qload.q2(QT * half + ft, hd * DH + 16 * DFULL);                          // (+ 2 g)
     }
+  };
+  auto prefetch = [&](const Geo& q, int hd, int half) {
+    load_q(hd, half);
     load_k(q, hd, q.cdiag, KA);  // the first step processes the diagonal chunk
     load_v(q, hd, q.cdiag, VA);
 #if EDTTS_KV2
@@ -697,7 +702,7 @@ EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, cons
       auto step = [&](auto fold_tag, int c, int cnext, KVFrag<C>& KA, VFrag<C>& VA) {  // c: this step's chunk, cnext: the chunk to request into the buffers
         constexpr bool FOLD = decltype(fold_tag)::value;
 #ifdef EDTTS_STAMPS
-        if (hd == EDTTS_STAMP_HEAD) STAMPX(stamps, sidx++);
+        if (hd == STAMP_SEL_HEAD(stamp_sel)) STAMPX(stamps, sidx++, stamp_sel);
 #endif
         qk(fold_tag, q, c, KA, qa, qr, S, NM, nm);
         __builtin_amdgcn_sched_barrier(0);
@@ -706,7 +711,7 @@ EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, cons
 #endif
         __builtin_amdgcn_sched_barrier(0);
 #ifdef EDTTS_STAMPS
-        if (hd == EDTTS_STAMP_HEAD) STAMPX(stamps, sidx++);
+        if (hd == STAMP_SEL_HEAD(stamp_sel)) STAMPX(stamps, sidx++, stamp_sel);
 #endif
         // one VGPR copy of the scores serves exp2 and the rare rescale (the pin keeps hipcc from re-reading the accumulators
         // after the branch)
@@ -754,12 +759,15 @@ EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, cons
           // cross-lane max and the read-modify-write of O then stay out of the common path entirely.
           const float lim = 4294967296.f;  // 2^kDefer
           static_assert(kDefer == 32.f, "lim above is 2^kDefer");
-          bool over = false;
+          // ONE test per step: all probabilities are >= 0, so the sum over both query tiles exceeds the limit (or is not finite)
+          // whenever one of them does
+          f4 pt = splat(0.f);
 #pragma unroll
           for (int ft = 0; ft < QT; ++ft) {
             exp_and_sum(ft, 0.f);
-            over = over || !(hsum(ps[ft]) <= lim);
+            pt += ps[ft];
           }
+          const bool over = !(hsum(pt) <= lim);
           if (__any(over)) {
 #pragma unroll
             for (int ft = 0; ft < QT; ++ft) {
@@ -779,7 +787,7 @@ EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, cons
         for (int ft = 0; ft < QT; ++ft) lvec[ft] += ps[ft];
         __builtin_amdgcn_sched_barrier(0);
 #ifdef EDTTS_STAMPS
-        if (hd == EDTTS_STAMP_HEAD) STAMPX(stamps, sidx++);
+        if (hd == STAMP_SEL_HEAD(stamp_sel)) STAMPX(stamps, sidx++, stamp_sel);
 #endif
 #pragma unroll
         for (int t = 0; t < CH; ++t)
@@ -795,7 +803,7 @@ EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, cons
 #endif
         __builtin_amdgcn_sched_barrier(0);
 #ifdef EDTTS_STAMPS
-        if (hd == EDTTS_STAMP_HEAD) STAMPX(stamps, sidx++);
+        if (hd == STAMP_SEL_HEAD(stamp_sel)) STAMPX(stamps, sidx++, stamp_sel);
 #endif
       };
       // step s = 0: the diagonal chunk; steps 1 .. nchunk-1: the other chunks in ascending order
@@ -808,6 +816,9 @@ EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, cons
         if (st + 1 < nchunk) step(Yes{}, chunk_of(st + 1), chunk_of(st + 3), KA, VA);
       }
 #else
+      // (Requesting the NEXT head's first q / K / V^T tiles from the head's last step instead of from its projection phase -- so
+      // that the phase's weight-ring waits do not queue behind HBM-latency requests in the in-order vmcnt -- was built and measured:
+      // 0.9369 vs 0.9307 ms per launch, slower; the per-step q re-request it needs costs more than the phase gains.)
       step(No{}, cd, chunk_of(1), KA, VA);
       for (int st = 1; st < nchunk; ++st) step(Yes{}, chunk_of(st), chunk_of(st + 1), KA, VA);
 #endif
@@ -815,14 +826,14 @@ EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, cons
 #pragma unroll
       for (int ft = 0; ft < QT; ++ft) {
         const float lt = group_sum(hsum(lvec[ft]));
-        const float inv = lt > 0.f ? 1.0f / lt : 0.f;
+        const float inv = lt > 0.f ? 1.0f / lt : 0.f;  // (IEEE divide, once per head and row: its rounding is part of the parity record)
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) O[dt][QT * hf + ft] *= inv;
       }
     }
     // ---- project: h[nt] += Wo[:, head features] . O  (all NF frame tiles at once) ------------------------------------
 #ifdef EDTTS_STAMPS
-    if (hd == EDTTS_STAMP_HEAD) STAMPX(stamps, sidx++);  // (normalisation done: start of the projection phases)
+    if (hd == STAMP_SEL_HEAD(stamp_sel)) STAMPX(stamps, sidx++, stamp_sel);  // (normalisation done: start of the projection phases)
 #endif
     if (hd + 1 < C::HEADS) prefetch(geo[0], hd + 1, 0);
 #pragma unroll
@@ -831,7 +842,7 @@ EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, cons
       else ktile_phase<C::HT>(ring, O[dt], h);
     }
 #ifdef EDTTS_STAMPS
-    if (hd == EDTTS_STAMP_HEAD) STAMPX(stamps, sidx++);  // end of the head
+    if (hd == STAMP_SEL_HEAD(stamp_sel)) STAMPX(stamps, sidx++, stamp_sel);  // end of the head
 #endif
   }
 }

@@ -627,17 +627,21 @@ EDTTS_DEV void tail_apply(const KArgs& a, size_t idx, f4 ev) {
   }
 }
 
-struct QGlobal {  // q rows in global memory, row-major [Tp][H]
-  const float* base;  // row of query frame (frame tile 0, fq)
+struct QGlobal {  // q rows in global memory, row-major [Tp][H]: buffer loads (descriptor base = row m0 of the utterance)
+  __amdgpu_buffer_rsrc_t rs;
+  unsigned v4, v2;  // this lane's byte offsets: row fq, feature quad 4 g / pair 2 g
   int H;
-  EDTTS_DEV f4 q4(int ft, int col) const { return ldg4(base + (size_t)ft * 16 * H + col); }
-  EDTTS_DEV f2 q2(int ft, int col) const { return ldg2(base + (size_t)ft * 16 * H + col); }
+  EDTTS_DEV QGlobal(const float* row_m0, int H_, int fq, int g) : rs(make_rsrc(row_m0)), v4((unsigned)(fq * H_ + 4 * g) * 4u), v2((unsigned)(fq * H_ + 2 * g) * 4u), H(H_) {}
+  EDTTS_DEV f4 q4(int ft, int col) const { return bufld4(rs, v4, (unsigned)(ft * 16 * H + col) * 4u); }
+  EDTTS_DEV f2 q2(int ft, int col) const { return bufld2(rs, v2, (unsigned)(ft * 16 * H + col) * 4u); }
 };
-struct QLds {  // q tile in this wave's LDS region, [32][QLD]
-  const float* base;  // row fq
+struct QLds {  // q tile in this wave's LDS region, [32][ld]
+  const float* b4;  // row fq, column 4 g
+  const float* b2;  // row fq, column 2 g
   int ld;
-  EDTTS_DEV f4 q4(int ft, int col) const { return *reinterpret_cast<const f4*>(base + ft * 16 * ld + col); }
-  EDTTS_DEV f2 q2(int ft, int col) const { return *reinterpret_cast<const f2*>(base + ft * 16 * ld + col); }
+  EDTTS_DEV QLds(const float* tile, int ld_, int fq, int g) : b4(tile + fq * ld_ + 4 * g), b2(tile + fq * ld_ + 2 * g), ld(ld_) {}
+  EDTTS_DEV f4 q4(int ft, int col) const { return *reinterpret_cast<const f4*>(b4 + ft * 16 * ld + col); }
+  EDTTS_DEV f2 q2(int ft, int col) const { return *reinterpret_cast<const f2*>(b2 + ft * 16 * ld + col); }
 };
 
 // PART 0: the whole block in one launch.  PART 1: attention half (self + cross attention, h written back).  PART 2: FFN + tail
@@ -669,7 +673,7 @@ __global__ __launch_bounds__(C::THREADS) void k_layer(KArgs a) {
   float* qtile = smem + (size_t)C::WAVES * C::HT * NF * 256 + (size_t)wave * C::WF * QLDS;  // (only touched when C::Q_IN_LDS)
   const size_t rowbase = (size_t)b * a.Tp + m0 + fq;
 
-  STAMPX(a.stamps, 0);
+  STAMPX(a.stamps, 0, a.diag_skip);
   WStream<C> ring;
   ring.prime(a.stream, lane);
 
@@ -726,12 +730,12 @@ __global__ __launch_bounds__(C::THREADS) void k_layer(KArgs a) {
       for (int ft = 0; ft < NF; ++ft) h[nt][ft] = pb;
     }
     if (DIAG_ON(1)) {
-      QGlobal ql{a.q + rowbase * C::H, C::H};
+      QGlobal ql(a.q + ((size_t)b * a.Tp + m0) * C::H, C::H, fq, g);
       attention_fused<C, true>(ql, a.k + (size_t)b * a.Tp * C::H, a.vT + (size_t)b * C::VR * a.Tp, a.Tp, a.T, a.window, m0,
-                               lane, ring, h, a.stamps ? a.stamps + 8 : nullptr);
+                               lane, ring, h, a.stamps ? a.stamps + 8 : nullptr, a.diag_skip);
     }
     add_parked_h();
-    STAMPX(a.stamps, 1);
+    STAMPX(a.stamps, 1, a.diag_skip);
   } else {
 #pragma unroll
     for (int nt = 0; nt < C::HT; ++nt)
@@ -760,22 +764,22 @@ __global__ __launch_bounds__(C::THREADS) void k_layer(KArgs a) {
           }
       }
     }
-    STAMPX(a.stamps, 2);
+    STAMPX(a.stamps, 2, a.diag_skip);
 #pragma unroll
     for (int nt = 0; nt < C::HT; ++nt)
 #pragma unroll
       for (int ft = 0; ft < NF; ++ft) h[nt][ft] = splat(0.f);
     if constexpr (C::Q_IN_LDS) {
-      QLds ql{qtile + fq * QLDS, QLDS};
+      QLds ql(qtile, QLDS, fq, g);
       attention_fused<C, false>(ql, a.kc + (size_t)b * a.Sp * C::H, a.vcT + (size_t)b * C::VR * a.Sp, a.Sp, a.S, -1, m0, lane,
-                                ring, h, a.stamps ? a.stamps + 40 : nullptr);
+                                ring, h, a.stamps ? a.stamps + 40 : nullptr, a.diag_skip);
     } else {
-      QGlobal ql{a.q + rowbase * C::H, C::H};
+      QGlobal ql(a.q + ((size_t)b * a.Tp + m0) * C::H, C::H, fq, g);
       attention_fused<C, false>(ql, a.kc + (size_t)b * a.Sp * C::H, a.vcT + (size_t)b * C::VR * a.Sp, a.Sp, a.S, -1, m0, lane,
                                 ring, h);
     }
     add_parked_h();
-    STAMPX(a.stamps, 3);
+    STAMPX(a.stamps, 3, a.diag_skip);
   }
   if (PART == PART_ATTN) {  // hand the residual tile to the FFN half
     park_h();
@@ -824,7 +828,7 @@ __global__ __launch_bounds__(C::THREADS) void k_layer(KArgs a) {
       ktile_phase<C::HT>(ring, act, h);
     }
     add_parked_h();
-    STAMPX(a.stamps, 4);
+    STAMPX(a.stamps, 4, a.diag_skip);
   }
   // ---- tail ---------------------------------------------------------------------------------------------------
   if (!DIAG_ON(8)) return;
@@ -859,11 +863,11 @@ __global__ __launch_bounds__(C::THREADS) void k_layer(KArgs a) {
       }
     }
   }
-  STAMPX(a.stamps, 5);
+  STAMPX(a.stamps, 5, a.diag_skip);
 #ifdef EDTTS_STAMPS
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // stores drained
 #endif
-  STAMPX(a.stamps, 6);
+  STAMPX(a.stamps, 6, a.diag_skip);
 }
 
 #include "edtts_bf16.h"
@@ -1687,6 +1691,12 @@ struct Launcher {
 #ifdef EDTTS_DIAG
     const char* e = getenv("EDTTS_DIAG_SKIP");
     a->diag_skip = e ? atoi(e) : 0;
+#endif
+#ifdef EDTTS_STAMPS
+    {
+      auto env = [](const char* n, int d) { const char* e = getenv(n); return e ? atoi(e) : d; };
+      a->diag_skip = env("EDTTS_STAMP_HEAD", 1) | (env("EDTTS_STAMP_WAVE", 0) << 8) | (env("EDTTS_STAMP_BLOCK", 8) << 16);
+    }
 #endif
   }
 
