@@ -20,9 +20,11 @@
 // Ablation / diagnostic switches change results or add instrumentation ("wrong by construction"): they exist for scratch/ only and
 // need -DEDTTS_EXPERIMENTS next to them, so that a product build can never carry one by accident.
 #if !defined(EDTTS_EXPERIMENTS) && (defined(EDTTS_ABLATE_QKVSTORES) || defined(EDTTS_ABLATE_KVLOADS) || defined(EDTTS_DIAG) || \
+                                    (defined(EDTTS_KV2) && EDTTS_KV2) || (defined(EDTTS_PERSIST) && EDTTS_PERSIST) || \
+                                    (defined(EDTTS_H_DMA) && EDTTS_H_DMA) || (defined(EDTTS_SPLITLOAD) && !EDTTS_SPLITLOAD) || \
                                     defined(EDTTS_STAMPS) || defined(EDTTS16_ABLATE_BARRIER) || defined(EDTTS16_ABLATE_DMA) || \
                                     (defined(EDTTS16_SPLIT_BUILD) && EDTTS16_SPLIT_BUILD))
-#error "ablation / diagnostic / split-layer switches are scratch-only: add -DEDTTS_EXPERIMENTS"
+#error "ablation / diagnostic / measured-and-rejected variant switches are scratch-only: add -DEDTTS_EXPERIMENTS"
 #endif
 
 typedef float f4 __attribute__((ext_vector_type(4)));
@@ -121,9 +123,6 @@ EDTTS_DEV void dma_tile_to_lds(const float* src, int ld, f4* lds_wave) {
 // VGPR that never changes (+ a 12-bit immediate).  All the per-load address arithmetic of a stream is then SALU work -- the
 // global_load forms hipcc picks for "uniform base + lane offset" rebuild a 64-bit lane address with a VALU instruction per load
 // (v_lshl_add_u64: 12 per attention step, ~14 per FFN iteration in the round-2 kernel; VALU time is MFMA time on fp32).
-#ifndef EDTTS_BUFLOAD
-#define EDTTS_BUFLOAD 1
-#endif
 typedef unsigned u4v __attribute__((ext_vector_type(4)));
 typedef unsigned u2v __attribute__((ext_vector_type(2)));
 EDTTS_DEV __amdgpu_buffer_rsrc_t make_rsrc(const void* base) {
@@ -181,29 +180,17 @@ constexpr int kRefillBurst = EDTTS_RB;
 template <int RN>
 struct FragRing {
   static constexpr int RN_ = RN;
-#if EDTTS_BUFLOAD
   __amdgpu_buffer_rsrc_t rs;  // the kernel's fragment stream
   unsigned soff;              // byte offset of position 0 of the current phase (wave-uniform: SALU arithmetic)
   unsigned voff;              // lane * 16
-#else
-  const f4* p;  // lane-offset pointer to position 0 of the current phase
-#endif
   f4 r[RN];
   EDTTS_DEV f4 frag(int i) const {
-#if EDTTS_BUFLOAD
     return bufld4(rs, voff, soff + (unsigned)i * 1024u);
-#else
-    return p[i * 64];
-#endif
   }
   EDTTS_DEV void prime(const float* base, int lane) {
-#if EDTTS_BUFLOAD
     rs = make_rsrc(base);
     soff = 0;
     voff = (unsigned)lane * 16u;
-#else
-    p = reinterpret_cast<const f4*>(base) + lane;
-#endif
 #pragma unroll
     for (int i = 0; i < RN; ++i) r[i] = frag(i);
   }
@@ -222,11 +209,7 @@ struct FragRing {
     if ((i + 1) % B == 0) refill(i + 1 - B, i + 1);
     else if (i == N - 1) refill(N - N % B, N);
   }
-#if EDTTS_BUFLOAD
   EDTTS_DEV void advance(int n) { soff += (unsigned)n * 1024u; }
-#else
-  EDTTS_DEV void advance(int n) { p += n * 64; }
-#endif
 };
 
 // out^T tile (16 features x 16*NF frames) += sum_kt frag(kt) * in[kt]: one n-major phase of KT fragments.  At NF = 2 even /
@@ -505,26 +488,17 @@ EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, cons
   // 1.5 % faster on the layer kernel than per-load 64-bit address arithmetic on the lanes.
   const unsigned koff = (unsigned)(fq * H + 4 * g) * 4u, koff_rem = (unsigned)(fq * H + 2 * g) * 4u;
   const unsigned voff = (unsigned)(fq * ldv + 4 * g) * 4u, voff_rem = (unsigned)(vrow_rem * ldv + 4 * g) * 4u;
-#if EDTTS_BUFLOAD
   const __amdgpu_buffer_rsrc_t rsK = make_rsrc(Kb), rsV = make_rsrc(VTb);
-#endif
   auto load_k = [&](const Geo& q, int hd, int c, KVFrag<C>& f) {
     c = c < q.nchunk ? c : q.nchunk - 1;
 #pragma unroll
     for (int t = 0; t < CH; ++t) {
       int kt = q.kt_lo + c * CH + t;
       kt = kt < q.kt_hi ? kt : q.kt_hi - 1;
-#if EDTTS_BUFLOAD
       const unsigned so = (unsigned)((kt << 4) * H + hd * DH) * 4u;  // uniform byte offset of (key tile, head)
 #pragma unroll
       for (int a = 0; a < DFULL; ++a) f.ka[t][a] = bufld4(rsK, koff + 64u * a, so);
       if (DREM) f.kr[t] = bufld2(rsK, koff_rem + 64u * DFULL, so);
-#else
-      const float* ku = Kb + (size_t)(kt << 4) * H + hd * DH;  // uniform
-#pragma unroll
-      for (int a = 0; a < DFULL; ++a) f.ka[t][a] = ldg4_sbase(ku + 16 * a, koff);
-      if (DREM) f.kr[t] = ldg2_sbase(ku + 16 * DFULL, koff_rem);
-#endif
     }
   };
   auto load_v = [&](const Geo& q, int hd, int c, VFrag<C>& f) {
@@ -535,16 +509,40 @@ EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, cons
       kt = kt < q.kt_hi ? kt : q.kt_hi - 1;
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) {
-#if EDTTS_BUFLOAD
         const unsigned so = (unsigned)((hd * DH + 16 * dt) * ldv + (kt << 4)) * 4u;  // uniform
         f.v[t][dt] = bufld4(rsV, (DREM && dt == DT - 1) ? voff_rem : voff, so);
-#else
-        const float* vu = VTb + (size_t)(hd * DH + 16 * dt) * ldv + (kt << 4);  // uniform
-        f.v[t][dt] = ldg4_sbase(vu, (DREM && dt == DT - 1) ? voff_rem : voff);
-#endif
       }
     }
   };
+#ifndef EDTTS_SPLITLOAD
+#define EDTTS_SPLITLOAD 1
+#endif
+#define EDTTS_SPLIT_ON (EDTTS_SPLITLOAD && !EDTTS_KV2)
+#if EDTTS_SPLIT_ON
+  // The same requests in pieces, for re-requesting a buffer piece by piece as soon as the MFMAs that read that piece have been
+  // issued (see step): group a of the K fragments of both key tiles (a == DFULL: the 8-feature remainder), key tile t of V^T.
+  auto chunk_tile = [&](const Geo& q, int c, int t) {
+    c = c < q.nchunk ? c : q.nchunk - 1;
+    const int kt = q.kt_lo + c * CH + t;
+    return kt < q.kt_hi ? kt : q.kt_hi - 1;
+  };
+  auto load_k_group = [&](const Geo& q, int hd, int c, KVFrag<C>& f, int a) {
+#pragma unroll
+    for (int t = 0; t < CH; ++t) {
+      const unsigned so = (unsigned)((chunk_tile(q, c, t) << 4) * H + hd * DH) * 4u;
+      if (a < DFULL) f.ka[t][a < DFULL ? a : 0] = bufld4(rsK, koff + 64u * a, so);
+      else if (DREM) f.kr[t] = bufld2(rsK, koff_rem + 64u * DFULL, so);
+    }
+  };
+  auto load_v_tile = [&](const Geo& q, int hd, int c, VFrag<C>& f, int t) {
+    const int kt = chunk_tile(q, c, t);
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+      const unsigned so = (unsigned)((hd * DH + 16 * dt) * ldv + (kt << 4)) * 4u;
+      f.v[t][dt] = bufld4(rsV, (DREM && dt == DT - 1) ? voff_rem : voff, so);
+    }
+  };
+#endif
   // Mask of chunk c as the INITIAL accumulator of its K Q^T product: 0 where the key is visible, -inf elsewhere
   // (-inf + finite products = -inf), so no VALU work sits between the MFMA results and the softmax.  Interior chunks (every
   // key inside the band of every query of the half and below klim: 3 of the 5 chunks at window 64, all of the cross-attention
@@ -577,7 +575,7 @@ EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, cons
   // removes a v_sub per score from every step.  nm[ft] = -m as a scalar (edge chunks: the mask select picks it instead of 0),
   // NM[ft] = the same value as a whole accumulator tile (interior chunks).
   auto qk = [&](auto fold_tag, const Geo& q, int c, const KVFrag<C>& f, const f4 (&qa)[QT][DFULL > 0 ? DFULL : 1],
-                const f2 (&qr)[QT], f4 (&S)[CH][QT], const f4 (&NM)[QT], const float (&nm)[QT]) {
+                const f2 (&qr)[QT], f4 (&S)[CH][QT], const f4 (&NM)[QT], const float (&nm)[QT], auto&& after_group) {
     static_assert(DFULL >= 1, "head_dim >= 16 expected");
     constexpr bool FOLD = decltype(fold_tag)::value;
     const int cc = c < q.nchunk ? c : q.nchunk - 1;
@@ -604,6 +602,7 @@ EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, cons
         for (int t = 0; t < CH; ++t)
 #pragma unroll
           for (int ft = 0; ft < QT; ++ft) S[t][ft] = EDTTS_MFMA(f.ka[t][a][b], qa[ft][a][b], S[t][ft]);
+        if (b == 3) after_group(a);  // the MFMAs that read fragment group a have been issued
       }
     if (DREM) {
 #pragma unroll
@@ -612,6 +611,7 @@ EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, cons
         for (int t = 0; t < CH; ++t)
 #pragma unroll
           for (int ft = 0; ft < QT; ++ft) S[t][ft] = EDTTS_MFMA(f.kr[t][b], qr[ft][b], S[t][ft]);
+      after_group(DFULL);
     }
   };
 
@@ -704,12 +704,24 @@ EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, cons
 #ifdef EDTTS_STAMPS
         if (hd == STAMP_SEL_HEAD(stamp_sel)) STAMPX(stamps, sidx++, stamp_sel);
 #endif
-        qk(fold_tag, q, c, KA, qa, qr, S, NM, nm);
+#if EDTTS_SPLIT_ON
+        // Each K fragment group is re-requested right after the score MFMAs that read it were issued (3 bursts of 2 requests inside
+        // the 40-MFMA run instead of one burst of 6 behind it): the group the next step needs FIRST is in flight ~1 000 cycles
+        // longer.  PMC: s_waitcnt took 6 % of the wave's cycles, most of it here (profiles/r03_diag_phases.txt).
+        qk(fold_tag, q, c, KA, qa, qr, S, NM, nm, [&](int a) {
+          __builtin_amdgcn_sched_barrier(0);
+          load_k_group(q, hd, cnext, KA, a);
+          __builtin_amdgcn_sched_barrier(0);
+        });
+        __builtin_amdgcn_sched_barrier(0);
+#else
+        qk(fold_tag, q, c, KA, qa, qr, S, NM, nm, [](int) {});
         __builtin_amdgcn_sched_barrier(0);
 #ifndef EDTTS_ABLATE_KVLOADS  // timing ablation only
         load_k(q, hd, cnext, KA);  // (the last step re-reads its own tiles)
 #endif
         __builtin_amdgcn_sched_barrier(0);
+#endif
 #ifdef EDTTS_STAMPS
         if (hd == STAMP_SEL_HEAD(stamp_sel)) STAMPX(stamps, sidx++, stamp_sel);
 #endif
@@ -790,15 +802,21 @@ EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, cons
         if (hd == STAMP_SEL_HEAD(stamp_sel)) STAMPX(stamps, sidx++, stamp_sel);
 #endif
 #pragma unroll
-        for (int t = 0; t < CH; ++t)
+        for (int t = 0; t < CH; ++t) {
 #pragma unroll
           for (int r = 0; r < 4; ++r)
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
               for (int ft = 0; ft < QT; ++ft) O[dt][QT * hf + ft] = EDTTS_MFMA(VA.v[t][dt][r], P[t][ft][r], O[dt][QT * hf + ft]);
+#if EDTTS_SPLIT_ON
+          __builtin_amdgcn_sched_barrier(0);
+          load_v_tile(q, hd, cnext, VA, t);  // this key tile's V^T fragments have been read: re-request them now
+          __builtin_amdgcn_sched_barrier(0);
+#endif
+        }
         __builtin_amdgcn_sched_barrier(0);
-#ifndef EDTTS_ABLATE_KVLOADS
+#if !EDTTS_SPLIT_ON && !defined(EDTTS_ABLATE_KVLOADS)
         load_v(q, hd, cnext, VA);
 #endif
         __builtin_amdgcn_sched_barrier(0);

@@ -649,23 +649,15 @@ struct QLds {  // q tile in this wave's LDS region, [32][ld]
 // layer, which buys the FFN / QKV weight stream twice the MFMAs per fragment without inflating the attention's registers.
 enum { PART_ALL = 0, PART_ATTN = 1, PART_FFN = 2 };
 
-#ifndef EDTTS_GCLUMP
-#define EDTTS_GCLUMP 1
-#endif
 // Where the residual tile waits while a branch accumulates (measured on one MI355X, B=256, T=512, whole generate_mel call):
 //   in LDS, next to the (unpadded) cross-attention q tiles -- 160 KiB per block at H = 160 (Cfg::Q_IN_LDS)           16.42 ms
 //   in LDS, with the cross-attention q rows going through global memory (this wave's dead self-attention q rows)     16.53 ms
 //   in the wave's own rows of the h buffer (global), q tiles padded in LDS                                           16.6 ms
 // The first form is used where it fits, the second otherwise (hidden 256: four waves x 32 KiB of residual tiles).
 template <class C, int TAIL, int PART>
-__global__ __launch_bounds__(C::THREADS) void k_layer(KArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+EDTTS_DEV void layer_tile(const KArgs& a, float* smem, int wave, int lane, int b, int m0) {
   constexpr int NF = C::NF;
-  const TileId tl = wave_tile(a.B, a.Tp, C::WAVES, C::WF);
-  if (!tl.valid) return;
-  const int lane = threadIdx.x & 63, fq = lane & 15, g = lane >> 4;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int b = tl.b, m0 = tl.m0;
+  const int fq = lane & 15, g = lane >> 4;
   // this wave's parking place for the residual tile, in REGISTER layout (element [nt][ft] of lane l at ((nt*NF + ft)*64 + l) * 16 B:
   // conflict-free b128 accesses, no padding)
   f4* const stash = reinterpret_cast<f4*>(smem) + (size_t)wave * C::HT * NF * 64 + lane;
@@ -803,28 +795,19 @@ __global__ __launch_bounds__(C::THREADS) void k_layer(KArgs a) {
 #pragma unroll
       for (int ft = 0; ft < NF; ++ft) v[ft] = gt[ft] = splat(0.f);
       gemm_phase_pair<C::HT>(ring, hn, v, gt);
-#if EDTTS_GCLUMP
       __builtin_amdgcn_sched_barrier(0);  // one VALU clump between the two MFMA phases: every MFMA<->VALU switch costs ~8 cycles
-#endif
 #pragma unroll
       for (int ft = 0; ft < NF; ++ft) {
         v[ft] += vb;  // bias after the GEMM: its load is off the MFMA critical path
         gt[ft] += gb;
-#if EDTTS_GCLUMP
         // SwiGLU: value * silu(gate) (transformer.py:21-23), written on vectors so that the mul / add halves pack (v_pk_*)
         const f4 e = {fast_exp2(gt[ft][0] * -1.4426950408889634f), fast_exp2(gt[ft][1] * -1.4426950408889634f),
                       fast_exp2(gt[ft][2] * -1.4426950408889634f), fast_exp2(gt[ft][3] * -1.4426950408889634f)};
         const f4 d = e + 1.0f;
         const f4 rc = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1]), __builtin_amdgcn_rcpf(d[2]), __builtin_amdgcn_rcpf(d[3])};
         act[ft] = (v[ft] * gt[ft]) * rc;
-#else
-#pragma unroll
-        for (int r = 0; r < 4; ++r) act[ft][r] = v[ft][r] * silu(gt[ft][r]);  // SwiGLU: value * silu(gate), transformer.py:21-23
-#endif
       }
-#if EDTTS_GCLUMP
       __builtin_amdgcn_sched_barrier(0);
-#endif
       ktile_phase<C::HT>(ring, act, h);
     }
     add_parked_h();
@@ -868,6 +851,29 @@ __global__ __launch_bounds__(C::THREADS) void k_layer(KArgs a) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // stores drained
 #endif
   STAMPX(a.stamps, 6, a.diag_skip);
+}
+
+// EDTTS_PERSIST = 1 (experiment): as many blocks as the device holds at once, each wave walking its tiles in a loop (static
+// assignment: tile, tile + waves in flight, ...) -- saves the block turnover between a wave's tiles.
+#ifndef EDTTS_PERSIST
+#define EDTTS_PERSIST 0
+#endif
+template <class C, int TAIL, int PART>
+__global__ __launch_bounds__(C::THREADS) void k_layer(KArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#if EDTTS_PERSIST
+  const int tpu = a.Tp / C::WF, ntiles = a.B * tpu;
+  for (int w = remap_block(blockIdx.x, gridDim.x) * C::WAVES + wave; w < ntiles; w += gridDim.x * C::WAVES) {
+    const int b = w / tpu;
+    layer_tile<C, TAIL, PART>(a, smem, wave, lane, b, (w - b * tpu) * C::WF);
+  }
+#else
+  const TileId tl = wave_tile(a.B, a.Tp, C::WAVES, C::WF);
+  if (!tl.valid) return;
+  layer_tile<C, TAIL, PART>(a, smem, wave, lane, tl.b, tl.m0);
+#endif
 }
 
 #include "edtts_bf16.h"
@@ -1572,9 +1578,6 @@ struct Workspace {
 // Measured at B=256, T=512 with -DEDTTS_NF_FFN=4: the 64-frame FFN half alone reaches 121.6 TFLOP/s (77 % of peak) against
 // ~80 % MFMA-busy inside the fused kernel, but attention half 0.613 ms + FFN half 0.462 ms = 1.075 ms per layer loses to the
 // fused 1.046 ms: the second kernel's start-up (exposed loads of 4096 waves at once) and drain cost more than the stream gains.
-#ifndef EDTTS_GCLUMP
-#define EDTTS_GCLUMP 1
-#endif
 #ifndef EDTTS_NF_FFN
 #define EDTTS_NF_FFN 0
 #endif
@@ -1718,6 +1721,11 @@ struct Launcher {
     base_args(lo, blob, ws, wsb, B, T, S, window, &a);
     a.x = x; a.cond = cond_row; a.cond_bstride = cond_bstride;
     const int g = grid(B, ws.Tp);
+#if EDTTS_PERSIST
+    const int g_layer = g < wave_slots() / C::WAVES ? g : wave_slots() / C::WAVES;
+#else
+    const int g_layer = g;
+#endif
     const size_t qk_set = (size_t)B * ws.Tp * lo.H, v_set = (size_t)B * ws.VR * ws.Tp;
     auto set_qkv = [&](int in_set, int out_set) {
       a.q = wsb + ws.q + in_set * qk_set; a.k = wsb + ws.k + in_set * qk_set; a.vT = wsb + ws.vT + in_set * v_set;
@@ -1778,7 +1786,7 @@ struct Launcher {
 #undef EDTTS_LAUNCH_FFN
         g_prof.kind = 0;
       } else {
-#define EDTTS_LAUNCH_ALL(TL) PROF_LAUNCH(st, hipLaunchKernelGGL((k_layer<C, TL, PART_ALL>), dim3(g), dim3(C::THREADS), layer_lds(), st, a))
+#define EDTTS_LAUNCH_ALL(TL) PROF_LAUNCH(st, hipLaunchKernelGGL((k_layer<C, TL, PART_ALL>), dim3(g_layer), dim3(C::THREADS), layer_lds(), st, a))
         switch (t_eff) {
           case TAIL_QKV: EDTTS_LAUNCH_ALL(TAIL_QKV); break;
           case TAIL_EPS: EDTTS_LAUNCH_ALL(TAIL_EPS); break;
