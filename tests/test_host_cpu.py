@@ -234,7 +234,8 @@ def test_no_product_kernel_uses_scratch():
         pytest.skip("library not built by build() in this checkout")
     res = G.kernel_resources(open(G.RESOURCE_LOG).read())
     layer = [k for k in res if "k_layer" in k]
-    assert len(layer) >= 12 and all(v.get("spill", 0) == 0 for v in res.values())
+    assert len(layer) >= 12 and all(v.get("scratch", 0) <= 64 for v in res.values())
+    assert all(v.get("spill", 0) == 0 or v.get("scratch", 0) == 0 for v in res.values())  # "spills" only into free AGPRs, never to memory
     # a reserved-but-unused emergency slot (ScratchSize > 0, zero spills, no scratch_* instruction: build() checks the assembly) is
     # tolerated for at most a couple of cold instances -- never for the headline kernels
     reserved = [k for k, v in res.items() if v.get("scratch", 0) > 0]
@@ -243,9 +244,11 @@ def test_no_product_kernel_uses_scratch():
     # the rule itself: an assembly with a scratch instruction fails, one without passes
     asm_ok, asm_bad = "_Z3foo:\n\tv_mov_b32 v0, v1\n\ts_endpgm\n", "_Z3foo:\n\tscratch_store_dword off, v0, s0\n\ts_endpgm\n"
     nospill = sample.replace("VGPRs Spill: 18", "VGPRs Spill: 0")
-    G.check_no_scratch(nospill, asm_ok)
+    G.check_no_scratch(nospill.replace("]: 76", "]: 36"), asm_ok)  # an untouched emergency slot passes
     with pytest.raises(RuntimeError, match="scratch instructions"):
-        G.check_no_scratch(nospill, asm_bad)
+        G.check_no_scratch(nospill.replace("]: 76", "]: 16"), asm_bad)
+    with pytest.raises(RuntimeError, match="76 B/lane"):
+        G.check_no_scratch(nospill, asm_ok)  # more than an emergency slot
     # the product library carries no experiment instantiations (two-launch layer halves, stand-alone attention kernels)
     assert not any("k_attn16" in k for k in res)
     assert not any(re.search(r"k_layerIN5edtts3CfgI[^E]*EELi\dELi[12]E", k) for k in res), "PART_ATTN / PART_FFN instances in the product build"
