@@ -66,7 +66,9 @@ struct Cfg16 {
 #define EDTTS16_W1 4   // waves per block of the NF = 1 variant: 8 = one block per CU, two waves per SIMD in lockstep; 4 = two independent blocks per CU
 #endif
   static constexpr int WAVES = NF == 2 ? 4 : EDTTS16_W1, THREADS = 64 * WAVES;
-  static constexpr int MIN_WAVES_PER_SIMD = NF == 2 ? 1 : 2;
+  // (the eight-wave NF = 1 block is the two-waves-per-SIMD experiment: 256 registers each; the four-wave one -- the run-time choice
+  // for small grids -- keeps the whole register file: under a 256-register cap it spills to scratch)
+  static constexpr int MIN_WAVES_PER_SIMD = (NF == 1 && WAVES == 8) ? 2 : 1;
   // Weight stream: every GEMM unit of the kernels (an n-tile pair over all k-tiles, or one k-tile over all n-tiles) consumes
   // exactly PH = HT fragments (1 KiB each) -- one PHASE.  The block shares one LDS ring of NS phase slots (see LdsRing).
   static constexpr int PH = HT;                 // fragments per phase

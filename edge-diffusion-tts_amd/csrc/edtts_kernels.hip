@@ -1842,15 +1842,33 @@ struct Launcher16 {
   using LmsStep = LmsStepArgs;
   using C2 = Cfg<C::H, C::HEADS, C::MEL, 2>;  // geometry of the (fp32-arithmetic) context kernel
   static int grid(int B, int Tp) { return (B * (Tp / C::WF) + C::WAVES - 1) / C::WAVES; }
+  // Small grids: the 16-frames-per-wave instance (two independent four-wave blocks per CU, bitwise the same results) when the
+  // 32-frame waves would leave half of the SIMDs without one (B * T <= 16 k frames on an MI355X).
+  static constexpr bool HAS_SMALL = C::NF == 2 && C::H == 256;
+  using Small = edtts16::Cfg16<C::H, C::HEADS, C::MEL, 1>;
+  static int simds() {
+    static int n[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 1024;
+    if (!n[dev]) {
+      int cus = 0;
+      n[dev] = (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) ? 4 * cus : 1024;
+    }
+    return n[dev];
+  }
   static int set_attrs() {  // the weight ring takes > 64 KiB of dynamic LDS: opt in once per device
     static bool done[64] = {};
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
     if (dev < 0 || dev >= 64) return fail(EDTTS_ERR_UNSUPPORTED, "device ordinal %d out of range", dev);
     if (done[dev]) return EDTTS_OK;
+    if constexpr (HAS_SMALL) {
+      int rc = Launcher16<Small>::set_attrs();
+      if (rc) return rc;
+    }
     const int lds = C::LDS_BYTES;
     HIP_TRY(hipFuncSetAttribute((const void*)edtts16::k_prologue16<C>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    HIP_TRY(hipFuncSetAttribute((const void*)k_ctx16<C>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    if constexpr (C::NF == 2) HIP_TRY(hipFuncSetAttribute((const void*)k_ctx16<C>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     HIP_TRY(hipFuncSetAttribute((const void*)edtts16::k_layer16<C, TAIL_QKV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     HIP_TRY(hipFuncSetAttribute((const void*)edtts16::k_layer16<C, TAIL_EPS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     HIP_TRY(hipFuncSetAttribute((const void*)edtts16::k_layer16<C, TAIL_DDIM>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -1891,10 +1909,12 @@ struct Launcher16 {
     if (EDTTS16_CTX_F32) {
       hipLaunchKernelGGL((k_ctx<C2, true>), dim3((B * (ws.Sp / 32) + kCtxWaves - 1) / kCtxWaves), dim3(64 * kCtxWaves), 0, st, a);
       LAUNCH_CHECK("k_ctx<bf16 out>");
-    } else {
+    } else if constexpr (C::NF == 2) {  // (the context cache is always built by the 32-token-per-wave launcher)
       a.stream16 = blob + lo.s_ctx16;
       hipLaunchKernelGGL((k_ctx16<C>), dim3((B * (ws.Sp / 32) + C::WAVES - 1) / C::WAVES), dim3(C::THREADS), C::LDS_BYTES, st, a);
       LAUNCH_CHECK("k_ctx16");
+    } else {
+      return fail(EDTTS_ERR_UNSUPPORTED, "internal: context cache requested from the 16-frame launcher");
     }
     return EDTTS_OK;
   }
@@ -1902,6 +1922,11 @@ struct Launcher16 {
                      const float* x, const float* cond_row, int cond_bstride, int tail, float* eps, float* x_prev, float* x0,
                      const float* coef, hipStream_t st, const DdpmStep* ddpm = nullptr, const LmsStep* lms = nullptr,
                      const VpredStepArgs* vp = nullptr) {
+    if constexpr (HAS_SMALL) {
+      if (2 * B * (ws.Tp / C::WF) <= simds())
+        return Launcher16<Small>::forward(lo, blob, ws, wsb, B, T, S, window, x, cond_row, cond_bstride, tail, eps, x_prev, x0, coef, st,
+                                          ddpm, lms, vp);
+    }
     KArgs a;
     memset(&a, 0, sizeof(a));
     a.B = B; a.T = T; a.Tp = ws.Tp; a.S = S; a.Sp = ws.Sp; a.window = window; a.max_pos = lo.MAXPOS;
