@@ -79,7 +79,8 @@ struct Cfg16 {
   // projection, read back head by head (64 registers less during the cross-attention; the ring gives up one slot for it)
   static constexpr int QLDS_BYTES = EDTTS16_QLDS ? WAVES * HEADS * NF * 1024 : 0;
   static constexpr int NS_MAX = (NF == 1 && WAVES == 4) ? 4 : 6;  // ring slots (phases): NS - 1 phases are in flight ahead of the consumers
-  static constexpr int PARAM_FLOATS = 4 * H + MEL;  // FFN up bias (stream order) + out_proj bias, staged in LDS (see k_layer16)
+  static constexpr int UPB_FLOATS = 8 * H;          // room for the FFN up bias at the largest ffn_mult (4): 2 * 4 * H floats
+  static constexpr int PARAM_FLOATS = UPB_FLOATS + MEL;  // FFN up bias (stream order) + out_proj bias, staged in LDS (see k_layer16)
   static constexpr int NS_FIT = (160 * 1024 - PARAM_FLOATS * 4 - QLDS_BYTES) / (PH * 1024);
   static constexpr int NS = NS_FIT < NS_MAX ? NS_FIT : NS_MAX;
   static constexpr int LDS_BYTES = NS * PH * 1024 + PARAM_FLOATS * 4 + QLDS_BYTES;
@@ -909,9 +910,9 @@ __global__ __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) void k_layer16(K
   // ring DMAs are in flight makes hipcc's waitcnt pass emit s_waitcnt vmcnt(0) (it cannot count the DMAs of earlier loop
   // iterations), which drains the whole prefetch ring once per phase -- measured: 2 800 cycles per 512-cycle phase.
   float* const params = reinterpret_cast<float*>(ring_lds16 + C::NS * C::PH * 64);
-  for (int i = threadIdx.x; i < 4 * C::H; i += C::THREADS) params[i] = a.up_b[i];
+  for (int i = threadIdx.x; i < 32 * a.ffn_tiles; i += C::THREADS) params[i] = a.up_b[i];  // 2 * ffn_mult * H
   if (TAIL != TAIL_QKV)
-    for (int i = threadIdx.x; i < C::MEL; i += C::THREADS) params[4 * C::H + i] = a.outp_b[i];
+    for (int i = threadIdx.x; i < C::MEL; i += C::THREADS) params[C::UPB_FLOATS + i] = a.outp_b[i];
   __syncthreads();
 
   // residual tile (fp32).  Unlike the fp32 kernel, the branches accumulate straight into it: the rounding of the partial sums at
@@ -1049,7 +1050,7 @@ __global__ __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) void k_layer16(K
 #pragma unroll
       for (int ft = 0; ft < NF; ++ft) h[nt][ft] += db;
     }
-    for (int jp = 0; jp < C::HT; ++jp) {  // 2H hidden features = HT k-tiles of the down projection
+    for (int jp = 0; jp < a.ffn_tiles / 2; ++jp) {  // ffn_mult * H hidden features = k-tiles (32 wide) of the down projection
       f4 act[2][NF];
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
@@ -1100,7 +1101,7 @@ __global__ __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) void k_layer16(K
       for (int u = 0; u < 2; ++u) {
         const int nt = 2 * p + u;
         if (nt >= C::MT) continue;  // the padding half of the last pair
-        const f4 ob = *reinterpret_cast<const f4*>(params + 4 * C::H + 16 * nt + 4 * g);
+        const f4 ob = *reinterpret_cast<const f4*>(params + C::UPB_FLOATS + 16 * nt + 4 * g);
 #pragma unroll
         for (int ft = 0; ft < NF; ++ft) {
           const int f = m0 + 16 * ft + fq;

@@ -103,6 +103,7 @@ struct LayerLayout {
 struct Layout {
   int BF16;  // 1: bf16 contractions (edtts_bf16.h): the fragment stream holds bf16 fragments of 16 outputs x 32 inputs
   int H, HEADS, MEL, L, DH, DHP, HT, MT, R, RT, SD, NTOK, MAXPOS, MAXCPOS, NSTEP;
+  int FM;  // ffn_mult: the FFN's hidden width is FM * H (layers/transformer.py:32-45: Linear(H, 2 FM H) -> SwiGLU -> Linear(FM H, H))
   size_t tok, semp, semp_b, t1T, t1b, t3T, t3b, step, inp, inp_b, pe, cpe, fnw, fnb, outp_b, freqs;
   LayerLayout layer[kMaxLayers];
   size_t s_outp;  // stream: final out_proj [MT n-tiles][HT]
@@ -117,7 +118,7 @@ static size_t align64(size_t v) { return (v + 63) & ~(size_t)63; }
 
 static int make_layout(const EdttsDims* d, Layout* lo) {
   if (!d) return fail(EDTTS_ERR_ARG, "dims is NULL");
-  if (d->ffn_mult != 2) return fail(EDTTS_ERR_UNSUPPORTED, "ffn_mult=%d (only 2 is compiled)", d->ffn_mult);
+  if (d->ffn_mult < 1 || d->ffn_mult > 4) return fail(EDTTS_ERR_UNSUPPORTED, "ffn_mult=%d outside [1, 4]", d->ffn_mult);
   if (d->layers < 1 || d->layers > kMaxLayers) return fail(EDTTS_ERR_UNSUPPORTED, "layers=%d out of [1,%d]", d->layers, kMaxLayers);
   if (d->hidden % 32 || d->n_mels % 16 || d->semantic_dim % 16 || d->heads < 1 || d->hidden % d->heads)
     return fail(EDTTS_ERR_UNSUPPORTED, "hidden=%d heads=%d n_mels=%d semantic_dim=%d: need hidden%%32==0, n_mels%%16==0, semantic_dim%%16==0",
@@ -131,7 +132,8 @@ static int make_layout(const EdttsDims* d, Layout* lo) {
   lo->H = d->hidden; lo->HEADS = d->heads; lo->MEL = d->n_mels; lo->L = d->layers;
   lo->DH = lo->H / lo->HEADS; lo->DHP = (lo->DH + 15) / 16 * 16; lo->HT = lo->H / 16; lo->MT = lo->MEL / 16;
   lo->R = lo->H / 2; lo->RT = lo->R / 16; lo->SD = d->semantic_dim; lo->NTOK = d->codebook_size;
-  lo->MAXPOS = d->max_pos; lo->MAXCPOS = d->max_ctx_pos; lo->NSTEP = d->n_step_emb;
+  lo->MAXPOS = d->max_pos; lo->MAXCPOS = d->max_ctx_pos; lo->NSTEP = d->n_step_emb; lo->FM = d->ffn_mult;
+  const size_t FM = lo->FM;
   const size_t H = lo->H, HT = lo->HT, MT = lo->MT, R = lo->R, RT = lo->RT, SD = lo->SD;
   const size_t KPT = (size_t)lo->HEADS * lo->DHP / 16;  // k-tiles of the head-padded projections
   size_t o = 0;
@@ -146,7 +148,7 @@ static int make_layout(const EdttsDims* d, Layout* lo) {
   for (int l = 0; l < lo->L; ++l) {
     LayerLayout& y = lo->layer[l];
     y.n1w = take(H); y.ada1T = take(H * 2 * H); y.ada1b = take(2 * H); y.proj_b = take(H); y.n2w = take(H);
-    y.n3w = take(H); y.ada3T = take(H * 2 * H); y.ada3b = take(2 * H); y.up_b = take(4 * H); y.down_b = take(H);
+    y.n3w = take(H); y.ada3T = take(H * 2 * H); y.ada3b = take(2 * H); y.up_b = take(2 * FM * H); y.down_b = take(H);
     y.kvd = take(RT * HT * kFrag); y.kvn = take(R); y.kvu = take(2 * HT * RT * kFrag);
   }
   // contiguous fragment stream: inp qkv(0) body(0) qkv(1) body(1) ... body(L-1) outp  + one ring of slack
@@ -160,7 +162,7 @@ static int make_layout(const EdttsDims* d, Layout* lo) {
       y.s_qkv = o; o += 3 * HT * KT * kFrag;  // q pairs | k pairs | v pairs
       y.s_body = o;
       y.s_ffn = o + 3 * HT * KT * kFrag;      // proj (k-major) | q_proj (pairs) | out_proj (k-major)
-      o = y.s_ffn + HT * (4 * KT + HT) * kFrag;  // per down k-tile: up value/gate of its two hidden tiles, then the down fragments
+      o = y.s_ffn + (FM * HT / 2) * (4 * KT + HT) * kFrag;  // per down k-tile (32 hidden features): up value/gate of its two hidden tiles, then the down fragments
     }
     lo->s_outp = o; o += MTP * 2 * KT * kFrag;  // final out_proj as n-tile pairs (the last pair may be half empty)
     o += 8 * HT * kFrag;  // the LDS ring prefetches NS phases (of HT fragments) past the last consumed one
@@ -171,7 +173,7 @@ static int make_layout(const EdttsDims* d, Layout* lo) {
     y.s_qkv = o; o += 3 * HT * HT * kFrag;
     y.s_body = o;
     y.s_ffn = o + (KPT * HT /*proj*/ + HT * HT /*q_proj*/ + KPT * HT /*out_proj*/) * kFrag;
-    o = y.s_ffn + (2 * HT * 3 * HT /*ffn*/) * kFrag;
+    o = y.s_ffn + (FM * HT * 3 * HT /*ffn: per hidden 16-tile 2 HT up + HT down fragments*/) * kFrag;
   }
   lo->s_outp = o; o += MT * HT * kFrag;
   o += 4 * HT * kFrag;  // the stream stages two phases (+ slot padding) past the last consumed fragment
@@ -400,6 +402,7 @@ struct KArgs {
   const float* cond;  // row base: [L][2][2H] per row
   int cond_bstride;   // floats between batch rows (0 = one row shared by the batch)
   int layer;
+  int ffn_tiles;  // 16-wide tiles of the FFN's hidden width: ffn_mult * H / 16
   int diag_skip;  // EDTTS_DIAG builds only: bit0 self-attn, bit1 q_proj+cross-attn, bit2 ffn, bit3 tail
   unsigned long long* stamps;  // EDTTS_STAMPS builds only: s_memtime stamps of block 0 / wave 0 (see edtts_debug_set_stamps)
   // weights
@@ -789,7 +792,7 @@ EDTTS_DEV void layer_tile(const KArgs& a, float* smem, int wave, int lane, int b
 #pragma unroll
       for (int ft = 0; ft < NF; ++ft) h[nt][ft] = db;
     }
-    for (int j = 0; j < 2 * C::HT; ++j) {
+    for (int j = 0; j < a.ffn_tiles; ++j) {  // (ffn_mult * HT hidden tiles: 2 HT for the reference's default)
       const f4 vb = ldg4(a.up_b + 32 * j + 4 * g), gb = ldg4(a.up_b + 32 * j + 16 + 4 * g);
       f4 v[NF], gt[NF], act[NF];
 #pragma unroll
@@ -1687,7 +1690,7 @@ struct Launcher {
                         int window, KArgs* a) {
     memset(a, 0, sizeof(*a));
     a->B = B; a->T = T; a->Tp = ws.Tp; a->S = S; a->Sp = ws.Sp; a->window = window; a->max_pos = lo.MAXPOS;
-    a->max_cpos = lo.MAXCPOS; a->n_tok = lo.NTOK; a->SD = lo.SD; a->L = lo.L;
+    a->max_cpos = lo.MAXCPOS; a->n_tok = lo.NTOK; a->SD = lo.SD; a->L = lo.L; a->ffn_tiles = lo.FM * lo.HT;
     a->h = wsb + ws.h;
     a->inp = blob + lo.inp; a->inp_b = blob + lo.inp_b; a->pe = blob + lo.pe;
     a->fnw = blob + lo.fnw; a->fnb = blob + lo.fnb; a->outp_b = blob + lo.outp_b;
@@ -1930,7 +1933,7 @@ struct Launcher16 {
     KArgs a;
     memset(&a, 0, sizeof(a));
     a.B = B; a.T = T; a.Tp = ws.Tp; a.S = S; a.Sp = ws.Sp; a.window = window; a.max_pos = lo.MAXPOS;
-    a.max_cpos = lo.MAXCPOS; a.n_tok = lo.NTOK; a.SD = lo.SD; a.L = lo.L;
+    a.max_cpos = lo.MAXCPOS; a.n_tok = lo.NTOK; a.SD = lo.SD; a.L = lo.L; a.ffn_tiles = lo.FM * lo.HT;
     a.h = wsb + ws.h;
     a.inp_b = blob + lo.inp_b; a.pe = blob + lo.pe;
     a.fnw = blob + lo.fnw; a.fnb = blob + lo.fnb; a.outp_b = blob + lo.outp_b;
@@ -2123,7 +2126,7 @@ int edtts_pack_weights(const EdttsDims* dims, const void* const* slots, int n_sl
   hipStream_t st = (hipStream_t)stream;
   float* blob = (float*)packed;
   auto G = [&](int i) { return (const float*)slots[i]; };
-  const int H = lo.H, HT = lo.HT, MT = lo.MT, R = lo.R, RT = lo.RT, SD = lo.SD, DH = lo.DH, DHP = lo.DHP;
+  const int H = lo.H, HT = lo.HT, MT = lo.MT, R = lo.R, RT = lo.RT, SD = lo.SD, DH = lo.DH, DHP = lo.DHP, FM = lo.FM;
   const int KPT = lo.HEADS * DHP / 16;
   HIP_TRY(hipMemsetAsync(blob, 0, lo.total * sizeof(float), st));
   TRY(copy_f(st, G(G_TOK), blob + lo.tok, (size_t)lo.NTOK * H));
@@ -2159,7 +2162,7 @@ int edtts_pack_weights(const EdttsDims* dims, const void* const* slots, int n_sl
     TRY(copy_f(st, W(L_N3_W), blob + y.n3w, H));
     TRY(transpose_f(st, W(L_N3P_W), blob + y.ada3T, 2 * H, H));
     TRY(copy_f(st, W(L_N3P_B), blob + y.ada3b, 2 * H));
-    hipLaunchKernelGGL(k_pack_upbias, dim3((4 * H + 255) / 256), dim3(256), 0, st, W(L_UP_B), blob + y.up_b, 2 * H);
+    hipLaunchKernelGGL(k_pack_upbias, dim3((2 * FM * H + 255) / 256), dim3(256), 0, st, W(L_UP_B), blob + y.up_b, FM * H);
     LAUNCH_CHECK("k_pack_upbias");
     TRY(copy_f(st, W(L_DOWN_B), blob + y.down_b, H));
     TRY(pack_gemm(st, W(L_KVD_W), H, R, H, RT, HT, 0, 0, 0, DH, DHP, blob + y.kvd));
@@ -2181,8 +2184,8 @@ int edtts_pack_weights(const EdttsDims* dims, const void* const* slots, int n_sl
       TRY(pack_gemm16(st, W(L_OP_W), H, H, H, HT, KT16, 1, s16));
       s16 += (size_t)HT * KT16 * kFrag;
       const int blk = 4 * KT16 + HT;  // per down k-tile: value/gate fragments of its two hidden tiles, then HT down fragments
-      TRY(pack_gemm16(st, W(L_UP_W), H, 4 * H, H, 4 * HT, KT16, 2, s16, blk, 4 * KT16));
-      TRY(pack_gemm16(st, W(L_DOWN_W), 2 * H, H, 2 * H, HT, HT, 3, s16, blk, 4 * KT16));
+      TRY(pack_gemm16(st, W(L_UP_W), H, 2 * FM * H, H, 2 * FM * HT, KT16, 2, s16, blk, 4 * KT16));
+      TRY(pack_gemm16(st, W(L_DOWN_W), FM * H, H, FM * H, HT, FM * HT / 2, 3, s16, blk, 4 * KT16));
       continue;
     }
     TRY(pack_gemm(st, W(L_QKV_W), H, 3 * H, H, 3 * HT, HT, 0, 0, 4, DH, DHP, blob + y.s_qkv, H, qscale));  // n-tile pairs
@@ -2193,8 +2196,8 @@ int edtts_pack_weights(const EdttsDims* dims, const void* const* slots, int n_sl
     s += (size_t)HT * HT * kFrag;
     TRY(pack_gemm(st, W(L_OP_W), H, H, lo.HEADS * DHP, HT, KPT, 0, 1, 1, DH, DHP, s));
     s += (size_t)KPT * HT * kFrag;
-    TRY(pack_gemm(st, W(L_UP_W), H, 4 * H, H, 4 * HT, HT, 1, 0, 2, DH, DHP, s));       // value/gate tiles interleaved
-    TRY(pack_gemm(st, W(L_DOWN_W), 2 * H, H, 2 * H, HT, 2 * HT, 0, 0, 3, DH, DHP, s));  // k-tile j after its up tiles
+    TRY(pack_gemm(st, W(L_UP_W), H, 2 * FM * H, H, 2 * FM * HT, HT, 1, 0, 2, DH, DHP, s));     // value/gate tiles interleaved
+    TRY(pack_gemm(st, W(L_DOWN_W), FM * H, H, FM * H, HT, FM * HT, 0, 0, 3, DH, DHP, s));  // k-tile j after its up tiles
   }
   return EDTTS_OK;
 }

@@ -12,6 +12,7 @@ Fixtures (inputs + the reference's outputs; no reference source is stored):
                     deterministic positive function of the chunk, `z_q_global` (HuBERT features) is synthetic.  Every torch.randn /
                     randn_like draw of the run and the per-chunk (mean, std) the loop derives are recorded, so that the build's
                     generate_long can be driven with exactly the same numbers.
+  forward_ffn_mult  decoder forwards at ffn_mult = 4 and 1 (the reference default is 2)
   dsconv_stride     DepthwiseSeparableConv(stride = 2, 3) (layers/conv.py:25-64), and shapes outside the fused kernel's class
   bf16_sampler      the reference's own generate_mel under torch.autocast("cpu", bfloat16) next to its fp32 run (4-step DDIM, hidden
                     64 / 2 heads of 32 / 2 layers, the smallest bf16-capable shape): the error distribution a bf16 implementation of
@@ -205,7 +206,24 @@ def dsconv_stride():
     np.savez_compressed(os.path.join(OUT, "dsconv_stride.npz"), **d)
 
 
-FIXTURES = {"longform_stitch": longform_stitch, "bf16_sampler": bf16_sampler, "dsconv_stride": dsconv_stride}
+@torch.no_grad()
+def forward_ffn_mult():
+    """Decoder forwards with ffn_mult = 4 and 1 (config.py:99; layers/transformer.py:32-45: hidden width ffn_mult * H)."""
+    d = {}
+    for tag, mult in (("m4", 4), ("m1", 1)):
+        cfg = ref.CFG(hidden=32, heads=2, layers=2, ffn_mult=mult, device="cpu")
+        dec = make_decoder(cfg, seed=8)
+        B, T, S = 2, 40, 20
+        xt = rnd((B, T, 80), 63, mult, 1.5)
+        tt = torch.tensor([850, 120])
+        si = torch.tensor([2, 0])
+        sem = rnd_idx((B, S), cfg.codebook_size, 63, 10 + mult)
+        d.update({f"{tag}_x_t": npf(xt), f"{tag}_t": npf(tt), f"{tag}_step_idx": npf(si), f"{tag}_sem_idx": npf(sem),
+                  f"{tag}_eps": npf(dec(xt, tt, sem, si))})
+    np.savez_compressed(os.path.join(OUT, "forward_ffn_mult.npz"), **d)
+
+
+FIXTURES = {"forward_ffn_mult": forward_ffn_mult, "longform_stitch": longform_stitch, "bf16_sampler": bf16_sampler, "dsconv_stride": dsconv_stride}
 
 
 if __name__ == "__main__":

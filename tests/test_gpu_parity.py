@@ -991,6 +991,30 @@ def test_bf16_no_cross_block_hazard_when_utterances_straddle_block_rounds():
         assert torch.equal(solo[0], big[u]), u
 
 
+def test_ffn_mult_1_and_4(golden):
+    """config.py:99 ffn_mult (FFN hidden width ffn_mult * H; the reference default 2 is what every other test runs): 4 and 1 against
+    reference goldens on the fp32 path, and ffn_mult = 4 through the bf16 kernels against the oracle."""
+    g = golden("forward_ffn_mult")
+    for tag, mult in (("m4", 4), ("m1", 1)):
+        cfg = CFG(hidden=32, heads=2, layers=2, ffn_mult=mult, device=DEV)
+        dec = make_decoder(cfg, 8)
+        e = dec(cu(g[f"{tag}_x_t"]), cu(g[f"{tag}_t"]), cu(g[f"{tag}_sem_idx"]), cu(g[f"{tag}_step_idx"])).cpu()
+        assert max_abs(e, g[f"{tag}_eps"]) < FWD_TOL, (tag, max_abs(e, g[f"{tag}_eps"]))
+    cfg = CFG(hidden=64, heads=2, layers=2, ffn_mult=4, device=DEV)
+    sd = synth_state_dict(cfg, 7)
+    gen = torch.Generator().manual_seed(12)
+    x, sem = torch.randn(2, 80, 80, generator=gen), torch.randint(0, 512, (2, 40), generator=gen)
+    t, si = torch.tensor([700, 30]), torch.tensor([1, 3])
+    ref = O.decoder_forward(sd, x, t, sem, si, heads=2)
+    dec = EdgeDiffusionDecoder(cfg, compute_dtype="bf16")
+    dec.load_state_dict(sd)
+    e = dec.to(DEV).eval()(cu(x), cu(t), cu(sem), cu(si)).cpu()
+    assert rms(e, ref) < BF16_RMS_TOL and max_abs(e, ref) < BF16_MAX_TOL, (rms(e, ref), max_abs(e, ref))
+    with pytest.raises(Exception, match="ffn_mult"):
+        bad = CFG(hidden=32, heads=2, layers=1, ffn_mult=5, device=DEV)
+        make_decoder(bad, 8)(torch.zeros(1, 32, 80, device=DEV), torch.zeros(1, dtype=torch.long, device=DEV), torch.zeros(1, 16, dtype=torch.long, device=DEV))
+
+
 def test_bf16_unsupported_head_dim_raises():
     from edge_diffusion_tts_amd.native import EdttsError
     cfg = CFG(device=DEV)  # head_dim 40
