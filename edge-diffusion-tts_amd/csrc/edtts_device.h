@@ -173,8 +173,11 @@ EDTTS_DEV float hmax(f4 v) { return fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
 // the top of each phase (measured 126 -> 137 TFLOP/s on the bare stream).  The sched_barrier pins the issue point:
 // without it the pre-RA scheduler sinks each load to its use RN fragments later, i.e. load -> s_waitcnt -> MFMA.
 // ---------------------------------------------------------------------------------------------------------
+// Refill burst: round 2 used 4 (an interruption of the MFMA run by VMEM issue cost ~20 cycles + 3 per load with the global_load
+// forms); with buffer loads (no address VALU) smaller bursts win because every slot is re-requested sooner: B=256, T=512 layer launch
+// 0.9280 ms at 4, 0.9186 at 2, 0.9184 at 1 (same device, interleaved runs).
 #ifndef EDTTS_RB
-#define EDTTS_RB 4
+#define EDTTS_RB 2
 #endif
 constexpr int kRefillBurst = EDTTS_RB;
 template <int RN>
