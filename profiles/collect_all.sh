@@ -1,6 +1,6 @@
 #!/bin/bash
 # Everything the round's evidence needs, in one gpurun call (from the repo root):  bash profiles/collect_all.sh r02
-TAG=${1:-r02}
+TAG=${1:-r03}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/all_$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"
@@ -13,6 +13,8 @@ timeout -k 10 400 python3 bench.py --config 3 --dtype f32 --no-pmc > "$OUT/bench
 timeout -k 10 200 python3 bench.py --config 1 --no-pmc > "$OUT/bench_cfg1.json" 2> "$OUT/bench_cfg1.err"
 timeout -k 10 200 python3 bench.py --batch 32 --no-pmc --no-cpu-baseline > "$OUT/bench_b32.json" 2> "$OUT/bench_b32.err"
 timeout -k 10 300 python3 bench.py --config 5 --no-pmc > "$OUT/bench_cfg5.json" 2> "$OUT/bench_cfg5.err"
+timeout -k 10 200 python3 bench.py --config 3 --batch 32 --steps 20 --no-pmc --no-cpu-baseline > "$OUT/bench_cfg3_b32.json" 2> "$OUT/bench_cfg3_b32.err"
+timeout -k 10 200 python3 bench.py --config 3 --batch 16 --steps 30 --no-pmc --no-cpu-baseline > "$OUT/bench_cfg3_b16.json" 2> "$OUT/bench_cfg3_b16.err"
 echo "== elementwise"; timeout -k 10 200 python3 scratch/bench_elementwise.py 2>/dev/null > "$OUT/elementwise.json"
 echo "== ring probe"; timeout -k 5 60 scratch/ring_probe > "$OUT/ring_probe.txt" 2>&1
 ls -la "$OUT"
