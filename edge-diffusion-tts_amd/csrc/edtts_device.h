@@ -72,10 +72,12 @@ struct Cfg {
 #define EDTTS_WMAX 2
 #endif
   static constexpr int WAVES0 = (HT * NF * 4 <= 160) ? 4 : 2;
-  // (The 16-frames-per-wave instances keep four-wave blocks = one block per CU: they fit 256 registers, and the dispatcher put the
-  // two waves of a SECOND two-wave block onto the same two SIMDs as the first -- B=32, T=512: 0.225 ms per layer launch against
-  // 0.154 with four-wave or one-wave blocks.  The 32-frame instances need > 256 registers, one wave per SIMD is all that fits.)
-  static constexpr int WAVES = NF == 1 ? WAVES0 : (WAVES0 < EDTTS_WMAX ? WAVES0 : EDTTS_WMAX);
+  // (The 16-frames-per-wave instances run ONE-wave blocks: they fit 256 registers, and with two-wave blocks the dispatcher put the
+  // two waves of a CU's second block onto the same two SIMDs as the first -- B=32, T=512: 0.225 ms per layer launch against 0.154
+  // with four-wave or one-wave blocks; one-wave blocks also spread a tiny grid over the most CUs: B=1, T=256 at 0.107 ms per
+  // layer launch against 0.125 with four-wave blocks.  The 32-frame instances need > 256 registers: one wave per SIMD is all
+  // that fits, whatever the block size.)
+  static constexpr int WAVES = NF == 1 ? 1 : (WAVES0 < EDTTS_WMAX ? WAVES0 : EDTTS_WMAX);
   // the cross-attention q tile goes through LDS when it fits next to the parked residual tiles (160 KiB per block at H = 160,
   // NF = 2), else through this wave's (already consumed) self-attention q rows in global memory
   static constexpr bool Q_IN_LDS = WF * H * 4 * 2 <= 40 * 1024;  // per wave: a quarter of the CU's 160 KiB (four waves per CU, in 1, 2 or 4 blocks)

@@ -486,6 +486,24 @@ def test_forward_maximum_lengths():
     assert max_abs(e2, O.decoder_forward(sd, x2, t, sem2, si)) < FWD_TOL
 
 
+def test_forward_more_than_32_key_chunks():
+    """The per-wave interior-chunk bit mask covers the first 32 chunks (1 024 keys: beyond the reference's own length limits); chunks
+    past it take the always-correct masked path.  Full attention over T = 1 100 frames (35 chunks) and a window of 600."""
+    for window in (None, 600):
+        cfg = CFG(hidden=32, heads=2, layers=1, attn_window_size=window, device=DEV)
+        sd = synth_state_dict(cfg, 3, max_pos=1200)
+        dec = EdgeDiffusionDecoder(cfg, max_len=1200)
+        dec.load_state_dict(sd)
+        dec = dec.to(DEV).eval()
+        gen = torch.Generator().manual_seed(44)
+        x = torch.randn(1, 1100, 80, generator=gen)
+        sem = torch.randint(0, 512, (1, 64), generator=gen)
+        t, si = torch.tensor([300]), torch.tensor([2])
+        e = dec(cu(x), cu(t), cu(sem), cu(si)).cpu()
+        ref = O.decoder_forward(sd, x, t, sem, si, heads=2, window=window)
+        assert max_abs(e, ref) < FWD_TOL, (window, max_abs(e, ref))
+
+
 def test_forward_full_attention_and_other_windows():
     """attn_window_size=None (full self-attention, layers/attention.py:94) and windows that are not multiples of the key tile."""
     for window in (None, 5, 37, 200):
