@@ -65,7 +65,7 @@ struct Cfg16 {
 #ifndef EDTTS16_W1
 #define EDTTS16_W1 4   // waves per block of the NF = 1 variant: 8 = one block per CU, two waves per SIMD in lockstep; 4 = two independent blocks per CU
 #endif
-  static constexpr int WAVES = NF == 2 ? 4 : EDTTS16_W1, THREADS = 64 * WAVES;
+  static constexpr int WAVES = NF == 1 ? EDTTS16_W1 : 4, THREADS = 64 * WAVES;
   // (the eight-wave NF = 1 block is the two-waves-per-SIMD experiment: 256 registers each; the four-wave one -- the run-time choice
   // for small grids -- keeps the whole register file: under a 256-register cap it spills to scratch)
   static constexpr int MIN_WAVES_PER_SIMD = (NF == 1 && WAVES == 8) ? 2 : 1;
@@ -73,11 +73,18 @@ struct Cfg16 {
   // exactly PH = HT fragments (1 KiB each) -- one PHASE.  The block shares one LDS ring of NS phase slots (see LdsRing).
   static constexpr int PH = HT;                 // fragments per phase
 #ifndef EDTTS16_QLDS
-#define EDTTS16_QLDS 1   // cross-attention q of all heads parked in LDS (1) instead of 64 registers (0)
+#define EDTTS16_QLDS 1   // cross-attention q of all heads parked in LDS (1) or in the wave's rows of the q buffer (0)
 #endif
   // cross-attention q operands of a wave's frames, all heads: [head][frame tile][lane] x 16 B -- written once after the q
   // projection, read back head by head (64 registers less during the cross-attention; the ring gives up one slot for it)
-  static constexpr int QLDS_BYTES = EDTTS16_QLDS ? WAVES * HEADS * NF * 1024 : 0;
+  // (NF = 4: 128 KiB would not fit beside the ring; the wave parks them in its own rows of the layer's q buffer instead, which the
+  // self-attention has finished with by then)
+  static constexpr bool QLDS = EDTTS16_QLDS && NF <= 2;
+#ifndef EDTTS16_FRAG_GROUP
+#define EDTTS16_FRAG_GROUP 4
+#endif
+  static constexpr int FRAG_GROUP = EDTTS16_FRAG_GROUP;  // NF = 4: weight fragments read from the ring per group (see gemm16_pair)
+  static constexpr int QLDS_BYTES = QLDS ? WAVES * HEADS * NF * 1024 : 0;
   static constexpr int NS_MAX = (NF == 1 && WAVES == 4) ? 4 : 6;  // ring slots (phases): NS - 1 phases are in flight ahead of the consumers
   static constexpr int UPB_FLOATS = 8 * H;          // room for the FFN up bias at the largest ffn_mult (4): 2 * 4 * H floats
   static constexpr int PARAM_FLOATS = UPB_FLOATS + MEL;  // FFN up bias (stream order) + out_proj bias, staged in LDS (see k_layer16)
@@ -86,7 +93,7 @@ struct Cfg16 {
   static constexpr int LDS_BYTES = NS * PH * 1024 + PARAM_FLOATS * 4 + QLDS_BYTES;
   static_assert(NS >= 3, "ring depth");
   static_assert(DH == 32, "the bf16 instance is built for head_dim 32 (one MFMA k-tile per head)");
-  static_assert(NF == 1 || NF == 2, "frame tiles per wave");
+  static_assert(NF == 1 || NF == 2 || NF == 4, "frame tiles per wave");
   static_assert(H % 64 == 0 && MEL % 16 == 0 && PH % WAVES == 0 && LDS_BYTES <= 160 * 1024, "dims vs ring");
 };
 
@@ -107,6 +114,24 @@ EDTTS_DEV f2s pack4(f4 a) {
 }
 EDTTS_DEV bf8 ldg_bf8(const __bf16* base, unsigned byte_off) {
   return *reinterpret_cast<const bf8*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+
+// 64-frame waves (NF = 4) keep the residual tile in the 256 AGPRs: it is written by the MFMAs of ktile16 (which name the class
+// themselves) and by acc_put, and read by the VALU through acc_get -- an opaque read, so that hipcc cannot keep a second, VGPR copy
+// of the tile alive from one reader to the next (it did: 460 spilled registers).  NF <= 2: plain values.
+template <bool PIN>
+EDTTS_DEV f4 acc_get(const f4& x) {
+  if constexpr (!PIN) return x;
+  else {
+    f4 r = x;
+    asm volatile("" : "+v"(r));
+    return r;
+  }
+}
+template <bool PIN>
+EDTTS_DEV void acc_put(f4& x, f4 v) {
+  x = v;
+  if constexpr (PIN) asm volatile("" : "+a"(x));
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -179,18 +204,45 @@ EDTTS_DEV void gemm16_pair(LdsRing<C>& ring, const bf8 (&in)[KT][C::NF], f4 (&a)
   // instead of read / wait / use per fragment pair, which exposes the LDS latency KT times per phase.  (Requesting the NEXT
   // phase's fragments right after this phase's MFMAs -- to take the barrier and the LDS round trip off the critical path -- was
   // measured 18 % slower: the 64 registers held across the phase boundary bring the spills back.)
-  f4 fg[2 * KT];
   const lds_cf4_t fb0 = phase_base(fr);
+  if constexpr (C::NF > 2) {
+    // 64 frames per wave: the residual tile alone is 256 registers, and a fragment feeds four MFMAs (64 cycles) -- the fragments are
+    // read in groups of FG, one group ahead of the MFMAs that consume them, instead of all up front (32 registers instead of 64)
+    constexpr int FG = C::FRAG_GROUP, NG = 2 * KT / FG;
+    static_assert(FG % 2 == 0 && (2 * KT) % FG == 0, "fragment groups");
+    f4 fg[2][FG];
 #pragma unroll
-  for (int i = 0; i < 2 * KT; ++i) fg[i] = fb0[i * 64];
-  __builtin_amdgcn_sched_barrier(0);
+    for (int i = 0; i < FG; ++i) fg[0][i] = fb0[i * 64];
 #pragma unroll
-  for (int kt = 0; kt < KT; ++kt) {
-    const bf8 fa = as_bf8(fg[2 * kt]), fb = as_bf8(fg[2 * kt + 1]);
+    for (int gi = 0; gi < NG; ++gi) {
+      if (gi + 1 < NG)
 #pragma unroll
-    for (int ft = 0; ft < C::NF; ++ft) {
-      a[ft] = SWAP ? EDTTS_MFMA16(in[kt][ft], fa, a[ft]) : EDTTS_MFMA16(fa, in[kt][ft], a[ft]);
-      b[ft] = SWAP ? EDTTS_MFMA16(in[kt][ft], fb, b[ft]) : EDTTS_MFMA16(fb, in[kt][ft], b[ft]);
+        for (int i = 0; i < FG; ++i) fg[(gi + 1) & 1][i] = fb0[((gi + 1) * FG + i) * 64];
+#pragma unroll
+      for (int kk = 0; kk < FG / 2; ++kk) {
+        const int kt = gi * (FG / 2) + kk;
+        const bf8 fa = as_bf8(fg[gi & 1][2 * kk]), fb = as_bf8(fg[gi & 1][2 * kk + 1]);
+#pragma unroll
+        for (int ft = 0; ft < C::NF; ++ft) {
+          a[ft] = SWAP ? EDTTS_MFMA16(in[kt][ft], fa, a[ft]) : EDTTS_MFMA16(fa, in[kt][ft], a[ft]);
+          b[ft] = SWAP ? EDTTS_MFMA16(in[kt][ft], fb, b[ft]) : EDTTS_MFMA16(fb, in[kt][ft], b[ft]);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  } else {
+    f4 fg[2 * KT];
+#pragma unroll
+    for (int i = 0; i < 2 * KT; ++i) fg[i] = fb0[i * 64];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+      const bf8 fa = as_bf8(fg[2 * kt]), fb = as_bf8(fg[2 * kt + 1]);
+#pragma unroll
+      for (int ft = 0; ft < C::NF; ++ft) {
+        a[ft] = SWAP ? EDTTS_MFMA16(in[kt][ft], fa, a[ft]) : EDTTS_MFMA16(fa, in[kt][ft], a[ft]);
+        b[ft] = SWAP ? EDTTS_MFMA16(in[kt][ft], fb, b[ft]) : EDTTS_MFMA16(fb, in[kt][ft], b[ft]);
+      }
     }
   }
 }
@@ -199,16 +251,61 @@ template <int NT, class C>
 EDTTS_DEV void ktile16(LdsRing<C>& ring, const bf8 (&in)[C::NF], f4 (&acc)[NT][C::NF]) {
   static_assert(NT == C::PH, "one k-tile over all n-tiles is one phase");
   const f4* fr = ring.acquire();
-  f4 fg[NT];
   const lds_cf4_t fb0 = phase_base(fr);
+  if constexpr (C::NF > 2) {  // (fragment groups: see gemm16_pair)
+    constexpr int FG = C::FRAG_GROUP, NG = NT / FG;
+    static_assert(NT % FG == 0, "fragment groups");
+    f4 fg[2][FG];
 #pragma unroll
-  for (int i = 0; i < NT; ++i) fg[i] = fb0[i * 64];
-  __builtin_amdgcn_sched_barrier(0);
+    for (int i = 0; i < FG; ++i) fg[0][i] = fb0[i * 64];
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    const bf8 fa = as_bf8(fg[nt]);
+    for (int gi = 0; gi < NG; ++gi) {
+      if (gi + 1 < NG)
 #pragma unroll
-    for (int ft = 0; ft < C::NF; ++ft) acc[nt][ft] = EDTTS_MFMA16(fa, in[ft], acc[nt][ft]);
+        for (int i = 0; i < FG; ++i) fg[(gi + 1) & 1][i] = fb0[((gi + 1) * FG + i) * 64];
+      // The residual tile is 256 registers = the whole accumulator half of the register file.  hipcc either keeps all MFMA results
+      // in AGPRs (then the 32 accumulators of the other GEMMs do not fit beside it) or none (-amdgpu-mfma-vgpr-form: then the tile
+      // competes with everything else for the 256 VGPRs); these MFMAs therefore name their accumulator class themselves.
+      static_assert(FG == 4 && C::NF == 4, "operand list of the block below");
+      const int n0 = gi * FG;
+      asm volatile(
+          "s_nop 1\n"
+          "v_mfma_f32_16x16x32_bf16 %0, %16, %20, %0\n"
+          "v_mfma_f32_16x16x32_bf16 %1, %16, %21, %1\n"
+          "v_mfma_f32_16x16x32_bf16 %2, %16, %22, %2\n"
+          "v_mfma_f32_16x16x32_bf16 %3, %16, %23, %3\n"
+          "v_mfma_f32_16x16x32_bf16 %4, %17, %20, %4\n"
+          "v_mfma_f32_16x16x32_bf16 %5, %17, %21, %5\n"
+          "v_mfma_f32_16x16x32_bf16 %6, %17, %22, %6\n"
+          "v_mfma_f32_16x16x32_bf16 %7, %17, %23, %7\n"
+          "v_mfma_f32_16x16x32_bf16 %8, %18, %20, %8\n"
+          "v_mfma_f32_16x16x32_bf16 %9, %18, %21, %9\n"
+          "v_mfma_f32_16x16x32_bf16 %10, %18, %22, %10\n"
+          "v_mfma_f32_16x16x32_bf16 %11, %18, %23, %11\n"
+          "v_mfma_f32_16x16x32_bf16 %12, %19, %20, %12\n"
+          "v_mfma_f32_16x16x32_bf16 %13, %19, %21, %13\n"
+          "v_mfma_f32_16x16x32_bf16 %14, %19, %22, %14\n"
+          "v_mfma_f32_16x16x32_bf16 %15, %19, %23, %15\n"
+          : "+a"(acc[n0][0]), "+a"(acc[n0][1]), "+a"(acc[n0][2]), "+a"(acc[n0][3]), "+a"(acc[n0 + 1][0]), "+a"(acc[n0 + 1][1]),
+            "+a"(acc[n0 + 1][2]), "+a"(acc[n0 + 1][3]), "+a"(acc[n0 + 2][0]), "+a"(acc[n0 + 2][1]), "+a"(acc[n0 + 2][2]),
+            "+a"(acc[n0 + 2][3]), "+a"(acc[n0 + 3][0]), "+a"(acc[n0 + 3][1]), "+a"(acc[n0 + 3][2]), "+a"(acc[n0 + 3][3])
+          : "v"(fg[gi & 1][0]), "v"(fg[gi & 1][1]), "v"(fg[gi & 1][2]), "v"(fg[gi & 1][3]), "v"(in[0]), "v"(in[1]), "v"(in[2]),
+            "v"(in[3]));
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // (the last results are 8 passes away: nothing the compiler places behind this block may read the tile earlier)
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+  } else {
+    f4 fg[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) fg[i] = fb0[i * 64];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const bf8 fa = as_bf8(fg[nt]);
+#pragma unroll
+      for (int ft = 0; ft < C::NF; ++ft) acc[nt][ft] = EDTTS_MFMA16(fa, in[ft], acc[nt][ft]);
+    }
   }
 }
 
@@ -217,13 +314,54 @@ template <class C>
 EDTTS_DEV void rms_norm_pack(const f4 (&x)[C::HT][C::NF], const float* __restrict__ w, const float* __restrict__ mod, int g,
                              bf8 (&y)[C::KT][C::NF]) {
   constexpr int NF = C::NF;
+  constexpr bool PIN = NF > 2;
   float rs[NF];
 #pragma unroll
   for (int ft = 0; ft < NF; ++ft) {
     float ss = 0.f;
 #pragma unroll
-    for (int t = 0; t < C::HT; ++t) ss += hsum(x[t][ft] * x[t][ft]);
+    for (int t = 0; t < C::HT; ++t) {
+      const f4 xv = acc_get<PIN>(x[t][ft]);
+      ss += hsum(xv * xv);
+    }
     rs[ft] = rsqrtf(group_sum(ss) * (1.0f / C::H) + 1e-6f);
+  }
+  if constexpr (NF > 2) {
+    // 64 frames per wave: 256 registers of residual + 128 of output leave no room for hipcc's habit of requesting all 48 parameter
+    // vectors up front (192 registers: it spilled 340) -- the k-tiles are pinned in order, each requesting the next one's parameters
+    f4 pw[2][2], psc[2][2], psh[2][2];
+    auto request = [&](int kt, int slot) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int t = 2 * kt + u;
+        pw[slot][u] = ldg4(w + 16 * t + 4 * g);
+        if (mod != nullptr) {
+          psc[slot][u] = ldg4(mod + 16 * t + 4 * g);
+          psh[slot][u] = ldg4(mod + C::H + 16 * t + 4 * g);
+        }
+      }
+    };
+    request(0, 0);
+#pragma unroll
+    for (int kt = 0; kt < C::KT; ++kt) {
+      if (kt + 1 < C::KT) request(kt + 1, (kt + 1) & 1);
+      f4 v[2][NF];
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int ft = 0; ft < NF; ++ft) {
+          f4 a = acc_get<PIN>(x[2 * kt + u][ft]) * rs[ft] * pw[kt & 1][u];
+          if (mod != nullptr) a = a * psc[kt & 1][u] + psh[kt & 1][u];
+          v[u][ft] = a;
+        }
+#pragma unroll
+      for (int ft = 0; ft < NF; ++ft) {
+        y[kt][ft] = pack8(v[0][ft], v[1][ft]);
+        asm volatile("" : "+v"(y[kt][ft]));  // (ordered with the opaque reads of the next k-tile: the arithmetic stays here)
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    return;
   }
 #pragma unroll
   for (int kt = 0; kt < C::KT; ++kt) {
@@ -252,20 +390,48 @@ template <class C>
 EDTTS_DEV void layer_norm_pack(const f4 (&x)[C::HT][C::NF], const float* __restrict__ w, const float* __restrict__ b, int g,
                                bf8 (&y)[C::KT][C::NF]) {
   constexpr int NF = C::NF;
+  constexpr bool PIN = NF > 2;
   float mu[NF], rs[NF];
 #pragma unroll
   for (int ft = 0; ft < NF; ++ft) {
     float s = 0.f;
 #pragma unroll
-    for (int t = 0; t < C::HT; ++t) s += hsum(x[t][ft]);
+    for (int t = 0; t < C::HT; ++t) s += hsum(acc_get<PIN>(x[t][ft]));
     mu[ft] = group_sum(s) * (1.0f / C::H);
     float v = 0.f;
 #pragma unroll
     for (int t = 0; t < C::HT; ++t) {
-      const f4 d = x[t][ft] - mu[ft];
+      const f4 d = acc_get<PIN>(x[t][ft]) - mu[ft];
       v += hsum(d * d);
     }
     rs[ft] = rsqrtf(group_sum(v) * (1.0f / C::H) + 1e-5f);
+  }
+  if constexpr (NF > 2) {  // (k-tiles pinned in order, parameters one k-tile ahead: see rms_norm_pack)
+    f4 pw[2][2], pbv[2][2];
+    auto request = [&](int kt, int slot) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        pw[slot][u] = ldg4(w + 16 * (2 * kt + u) + 4 * g);
+        pbv[slot][u] = ldg4(b + 16 * (2 * kt + u) + 4 * g);
+      }
+    };
+    request(0, 0);
+#pragma unroll
+    for (int kt = 0; kt < C::KT; ++kt) {
+      if (kt + 1 < C::KT) request(kt + 1, (kt + 1) & 1);
+      f4 v[2][NF];
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int ft = 0; ft < NF; ++ft) v[u][ft] = (acc_get<PIN>(x[2 * kt + u][ft]) - mu[ft]) * rs[ft] * pw[kt & 1][u] + pbv[kt & 1][u];
+#pragma unroll
+      for (int ft = 0; ft < NF; ++ft) {
+        y[kt][ft] = pack8(v[0][ft], v[1][ft]);
+        asm volatile("" : "+v"(y[kt][ft]));  // (ordered with the opaque reads of the next k-tile: the arithmetic stays here)
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    return;
   }
 #pragma unroll
   for (int kt = 0; kt < C::KT; ++kt) {
@@ -306,12 +472,14 @@ EDTTS_DEV void attention16(QF&& qf, const __bf16* __restrict__ Kb, const __bf16*
   const float NEG_INF = -__builtin_inff();
   // chunk geometry as in edtts_device.h attention_fused: partition and order are those of the enclosing 32-frame pair of query
   // tiles (mg), also when the wave owns one tile (NF = 1); the per-lane band limits use the wave's own rows
-  const int mg = m0 & ~31;
+  // (NF = 4: the wave's own 64 frames are the group -- one chunk walk for all four query tiles)
+  constexpr int GROUP = NF > 2 ? 16 * NF : 32;
+  const int mg = m0 & ~(GROUP - 1);
   int kt_lo, kt_hi;
   if (SELF && window >= 0) {
     const int lo = mg - window;
     kt_lo = ((lo > 0 ? lo : 0) >> 4) & ~1;
-    const int hi = mg + 31 + window;
+    const int hi = mg + GROUP - 1 + window;
     const int last = hi < nkeys - 1 ? hi : nkeys - 1;
     kt_hi = (last >> 4) + 1;
   } else {
@@ -398,9 +566,21 @@ EDTTS_DEV void attention16(QF&& qf, const __bf16* __restrict__ Kb, const __bf16*
   // the loop control and the rescale branch are paid once per 2 x 16 scores, and the step holds two independent
   // MFMA -> exp2 -> pack -> MFMA chains for the scheduler to interleave: with one wave per SIMD nothing else hides their latencies
   // (stand-alone attention, 4.5: a second instruction stream per SIMD is worth 1.45x).
-  static_assert(C::HEADS % 2 == 0, "head pairs");
-  constexpr int HP = 2;
-  bf8 KA0[HP][2], VA0[HP][2], KA1[HP][2], VA1[HP][2], q[HP][NF];
+  // (NF = 4: one head per step -- its four query tiles are the independent chains, and each K / V^T tile feeds four MFMAs)
+  constexpr int HP = NF > 2 ? 1 : 2;
+  static_assert(C::HEADS % HP == 0, "head pairs");
+  // K / V^T tiles are requested KD steps ahead into KD register buffer sets.  64-frame waves, cross-attention: 3 -- twice the
+  // frames per CU double the context K / V^T working set of an XCD (8 utterances x 512 KiB = its whole L2), and at two steps
+  // ahead the V^T tiles of every other step arrived 1 000 - 2 000 cycles late (rocprof: L2 hit rate 78 % -> 67 %, SQ_WAIT_ANY + 36 %)
+#ifndef EDTTS16_WIDE_KD
+#define EDTTS16_WIDE_KD 3
+#endif
+#ifndef EDTTS16_WIDE_KD_SELF
+#define EDTTS16_WIDE_KD_SELF 2
+#endif
+  constexpr int KD = NF > 2 ? (SELF ? EDTTS16_WIDE_KD_SELF : EDTTS16_WIDE_KD) : 2;
+  static_assert(KD == 2 || KD == 3, "K / V^T prefetch depth");
+  bf8 KA0[HP][2], VA0[HP][2], KA1[HP][2], VA1[HP][2], KA2[HP][2], VA2[HP][2], q[HP][NF];
   auto prefetch = [&](int hd) {
 #pragma unroll
     for (int h = 0; h < HP; ++h) {
@@ -410,6 +590,10 @@ EDTTS_DEV void attention16(QF&& qf, const __bf16* __restrict__ Kb, const __bf16*
       load_v(hd + h, chunk_of(0), VA0[h]);
       load_k(hd + h, chunk_of(1), KA1[h]);
       load_v(hd + h, chunk_of(1), VA1[h]);
+      if constexpr (KD == 3) {
+        load_k(hd + h, chunk_of(2), KA2[h]);
+        load_v(hd + h, chunk_of(2), VA2[h]);
+      }
     }
   };
   prefetch(0);
@@ -437,7 +621,8 @@ EDTTS_DEV void attention16(QF&& qf, const __bf16* __restrict__ Kb, const __bf16*
             for (int h = 0; h < HP; ++h) S[h][t][ft] = EDTTS_MFMA16(KA[h][t], q[h][ft], NM[h][ft]);
       } else {
         // the visibility predicates are the pair's; each head selects its own reference point
-        const int cc = clampc(c);
+        int cc = clampc(c);
+        if constexpr (NF > 2) asm volatile("" : "+s"(cc));  // (else the first step's 32-register mask tile is hoisted out of the head loop and spilled)
         const int k0 = (kt_lo + 2 * cc) << 4;
 #pragma unroll
         for (int ft = 0; ft < NF; ++ft) {
@@ -558,10 +743,17 @@ EDTTS_DEV void attention16(QF&& qf, const __bf16* __restrict__ Kb, const __bf16*
     // end of an odd step count runs fully masked: one step in 17 wasted in the cross-attention, 36.6 -> 35.9 ms per call.
     // (Measured before: the conditional step computed under its condition with its requests made unconditional: no gain;
     // unconditional step pairs plus a tail step, a fourth copy of the step: 53.6 ms, 202 spilled registers.)
-    step(true, chunk_of(0), chunk_of(2), KA0, VA0);
+    step(true, chunk_of(0), chunk_of(KD), KA0, VA0);
 #ifndef EDTTS16_EVEN_STEPS
 #define EDTTS16_EVEN_STEPS 1
 #endif
+    if constexpr (KD == 3) {  // (three steps per iteration; steps past the end run fully masked)
+      for (int st = 1; st < nchunk; st += 3) {
+        step(false, chunk_of(st), chunk_of(st + 3), KA1, VA1);
+        step(false, st + 1 < nchunk ? chunk_of(st + 1) : -1, chunk_of(st + 4), KA2, VA2);
+        step(false, st + 2 < nchunk ? chunk_of(st + 2) : -1, chunk_of(st + 5), KA0, VA0);
+      }
+    } else
     for (int st = 1; st < nchunk; st += 2) {
       step(false, chunk_of(st), chunk_of(st + 2), KA1, VA1);
 #if EDTTS16_EVEN_STEPS
@@ -790,8 +982,11 @@ EDTTS_DEV void qkv_tail16(Ring16<C>& ring, const bf8 (&hn)[C::KT][C::NF], const 
     for (int u = 0; u < 2; ++u) {
       // v^T image: [head p][32-key chunk][d-tile u][16 d][32 key slots]; key 16 t + 4 g + r of the chunk sits at slot 8 g + 4 t + r
       __bf16* dst = vo + ((size_t)(b * C::HEADS + p) * (a.Tp >> 5) + (m0 >> 5)) * 1024 + u * 512 + fq * 32 + 8 * g;
-      if (NF == 2) {
-        if (valid) *reinterpret_cast<f4*>(dst) = as_f4(pack8(acc[u][0], acc[u][NF - 1]));
+      if (NF >= 2) {
+        if (valid)
+#pragma unroll
+          for (int cp = 0; cp < NF / 2; ++cp)  // one 32-key chunk per pair of frame tiles
+            *reinterpret_cast<f4*>(dst + cp * 1024) = as_f4(pack8(acc[u][2 * cp], acc[u][(2 * cp + 1) % NF]));
       } else {  // one 16-frame tile per wave: its 4 keys per lane are half of the 8-slot group (t = tile parity inside the chunk)
         if (valid) *reinterpret_cast<f2s*>(dst + 4 * ((m0 >> 4) & 1)) = pack4(acc[u][0]);
       }
@@ -831,7 +1026,7 @@ __global__ __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) void k_prologue1
 #pragma unroll
   for (int nt = 0; nt < C::HT; ++nt)
 #pragma unroll
-    for (int ft = 0; ft < NF; ++ft) h[nt][ft] = ldg4(a.inp_b + 16 * nt + 4 * g);
+    for (int ft = 0; ft < NF; ++ft) acc_put<(NF > 2)>(h[nt][ft], ldg4(a.inp_b + 16 * nt + 4 * g));
 #pragma unroll
   for (int kt = 0; kt < C::MKT; ++kt) ktile16<C::HT>(ring, xin[kt], h);
 #pragma unroll
@@ -839,14 +1034,15 @@ __global__ __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) void k_prologue1
     int f = m0 + 16 * ft + fq;
     f = f < a.max_pos ? f : a.max_pos - 1;
 #pragma unroll
-    for (int nt = 0; nt < C::HT; ++nt) h[nt][ft] += ldg4(a.pe + (size_t)f * C::H + 16 * nt + 4 * g);
+    for (int nt = 0; nt < C::HT; ++nt)
+      acc_put<(NF > 2)>(h[nt][ft], acc_get<(NF > 2)>(h[nt][ft]) + ldg4(a.pe + (size_t)f * C::H + 16 * nt + 4 * g));
   }
   if (valid) {
     float* hp = a.h + ((size_t)b * a.Tp + m0 + fq) * C::H + 4 * g;
 #pragma unroll
     for (int nt = 0; nt < C::HT; ++nt)
 #pragma unroll
-      for (int ft = 0; ft < NF; ++ft) stg4(hp + 16 * nt + (size_t)ft * 16 * C::H, h[nt][ft]);
+      for (int ft = 0; ft < NF; ++ft) stg4(hp + 16 * nt + (size_t)ft * 16 * C::H, acc_get<(NF > 2)>(h[nt][ft]));
   }
   bf8 hn[C::KT][NF];
   rms_norm_pack<C>(h, a.n1w, a.cond + (size_t)b * a.cond_bstride, g, hn);
@@ -891,6 +1087,11 @@ __global__ __launch_bounds__(C::THREADS, EDTTS16_ATT_OCC) void k_attn16(KArgs a)
 // PART16_ALL: the whole layer in one launch.  Split layer: k_attn16<self> | PART16_MID (self out-projection, norm2, cross q) |
 // k_attn16<cross> | PART16_POST (cross out-projection, FFN, tail) -- same arithmetic in the same order, bitwise the same result.
 enum { PART16_ALL = 0, PART16_MID = 1, PART16_POST = 2 };
+// (register-pressure probes: -DEDTTS_EXPERIMENTS -DEDTTS16_PHASES=<mask> compiles only the masked phases of the layer -- 1 self-attention,
+// 2 cross-attention, 4 FFN, 8 tail; results wrong by construction)
+#ifndef EDTTS16_PHASES
+#define EDTTS16_PHASES 15
+#endif
 template <class C, int TAIL, int PART = PART16_ALL>
 __global__ __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) void k_layer16(KArgs a) {
   extern __shared__ __attribute__((aligned(16))) f4 ring_lds16[];
@@ -919,13 +1120,14 @@ __global__ __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) void k_layer16(K
   // the residual's magnitude (~1e-6) is three orders below the bf16 operand rounding, and a separate branch tile would cost 128
   // more registers (measured: spills, whose scratch reloads force s_waitcnt vmcnt(0) and drain the weight ring).
   constexpr int NF = C::NF;
+  constexpr bool PIN = NF > 2;  // (64-frame waves: the tile lives in the AGPRs, see acc_get)
   f4 h[C::HT][NF];
   float* const hp = a.h + rowbase * C::H + 4 * g;
 #pragma unroll
   for (int nt = 0; nt < C::HT; ++nt) {
     const f4 pb = PART == PART16_POST ? splat(0.f) : ldg4(a.proj_b + 16 * nt + 4 * g);
 #pragma unroll
-    for (int ft = 0; ft < NF; ++ft) h[nt][ft] = ldg4(hp + 16 * nt + (size_t)ft * 16 * C::H) + pb;
+    for (int ft = 0; ft < NF; ++ft) acc_put<PIN>(h[nt][ft], ldg4(hp + 16 * nt + (size_t)ft * 16 * C::H) + pb);
   }
   // split layer: this wave's attention output rows (all heads), fetched and WAITED FOR before the streaming loop (a global load
   // consumed inside it would make hipcc drain the ring with vmcnt(0) every phase), then projected head by head
@@ -948,9 +1150,15 @@ __global__ __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) void k_layer16(K
   STAMP16(0);
   // ---- x = x + attn(norm1(x, cond))   (transformer.py:142-146; q / k / v^T were produced by the previous kernel) ----
   if (PART == PART16_MID) project_attn_rows();
-  if (PART == PART16_ALL) {
+  if (PART == PART16_ALL && (EDTTS16_PHASES & 1)) {
     const __bf16* qrow = reinterpret_cast<const __bf16*>(a.q) + rowbase * C::H + 8 * g;
-    auto qf = [&](int hd, int ft) { return *reinterpret_cast<const bf8*>(qrow + (size_t)ft * 16 * C::H + hd * C::DH); };
+    // (64-frame waves: descriptor + scalar offset -- four row pointers held across the head loop were spilled and reloaded per head)
+    const __amdgpu_buffer_rsrc_t rsq = make_rsrc(reinterpret_cast<const __bf16*>(a.q) + ((size_t)b * a.Tp + m0) * C::H);
+    const unsigned qvoff = (unsigned)(fq * C::H + 8 * g) * 2u;
+    auto qf = [&](int hd, int ft) {
+      if constexpr (PIN) return as_bf8(bufld4(rsq, qvoff, (unsigned)(ft * 16 * C::H + hd * C::DH) * 2u));
+      else return *reinterpret_cast<const bf8*>(qrow + (size_t)ft * 16 * C::H + hd * C::DH);
+    };
     attention16<C, true>(qf, reinterpret_cast<const __bf16*>(a.k) + (size_t)b * a.Tp * C::H,
                          reinterpret_cast<const __bf16*>(a.vT) + (size_t)b * C::H * a.Tp, a.Tp, a.T, a.window, m0, lane,
                          [&](int, const bf8 (&ob)[NF]) { ktile16<C::HT>(ring, ob, h); }  // h += Wo[:, head] . O
@@ -985,10 +1193,14 @@ __global__ __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) void k_layer16(K
     ring.drain();
     return;
   }
-  if (PART == PART16_ALL) {
-#if EDTTS16_QLDS
+  if (PART == PART16_ALL && (EDTTS16_PHASES & 2)) {
+    // cross-attention q of all heads: written once after the q projection, read back head by head (64 / 128 registers less during
+    // the cross-attention).  QLDS: in this wave's LDS slice; else (NF = 4) in this wave's own rows of the layer's q buffer, which
+    // its self-attention has finished with (no other wave reads q rows; a padding wave stores nothing and reads what it finds).
     f4* const qlds = ring_lds16 + C::NS * C::PH * 64 + (C::PARAM_FLOATS + 3) / 4 +
                      (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * C::HEADS * NF) * 64 + lane;
+    const __amdgpu_buffer_rsrc_t rsp = make_rsrc(reinterpret_cast<const __bf16*>(a.q) + ((size_t)b * a.Tp + m0) * C::H);
+    const unsigned pvoff = (unsigned)(fq * C::H + 8 * g) * 2u;
     {
       bf8 hn[C::KT][NF];
       rms_norm_pack<C>(h, a.n2w, nullptr, g, hn);
@@ -998,39 +1210,21 @@ __global__ __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) void k_layer16(K
         for (int ft = 0; ft < NF; ++ft) acc[0][ft] = acc[1][ft] = splat(0.f);
         gemm16_pair<C::KT, false>(ring, hn, acc[0], acc[1]);
 #pragma unroll
-        for (int ft = 0; ft < NF; ++ft) qlds[(p * NF + ft) * 64] = as_f4(pack8(acc[0][ft], acc[1][ft]));
+        for (int ft = 0; ft < NF; ++ft) {
+          if constexpr (C::QLDS) qlds[(p * NF + ft) * 64] = as_f4(pack8(acc[0][ft], acc[1][ft]));
+          else if (valid)
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, pack8(acc[0][ft], acc[1][ft])),
+                                                   rsp, pvoff, (unsigned)(ft * 16 * C::H + p * C::DH) * 2u, 0);
+        }
       }
     }
-    STAMP16(2);
-    auto qf = [&](int hd, int ft) { return as_bf8(qlds[(hd * NF + ft) * 64]); };
-#else
-    bf8 qx[C::KT][NF];
-    {
-      bf8 hn[C::KT][NF];
-      rms_norm_pack<C>(h, a.n2w, nullptr, g, hn);
-      for (int p = 0; p < C::KT; ++p) {
-        f4 acc[2][NF];
-#pragma unroll
-        for (int ft = 0; ft < NF; ++ft) acc[0][ft] = acc[1][ft] = splat(0.f);
-        gemm16_pair<C::KT, false>(ring, hn, acc[0], acc[1]);
-        // (a runtime-indexed register array would go to scratch: write through a fully unrolled select)
-#pragma unroll
-        for (int pp = 0; pp < C::KT; ++pp)
-          if (pp == p) {
-#pragma unroll
-            for (int ft = 0; ft < NF; ++ft) qx[pp][ft] = pack8(acc[0][ft], acc[1][ft]);
-          }
-      }
-    }
+    // (the parked rows are read back by the lanes that wrote them; the stores have left the wave before the first read is issued)
+    if constexpr (!C::QLDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     STAMP16(2);
     auto qf = [&](int hd, int ft) {
-      bf8 r = qx[0][ft];
-#pragma unroll
-      for (int pp = 1; pp < C::KT; ++pp)
-        if (pp == hd) r = qx[pp][ft];
-      return r;
+      if constexpr (C::QLDS) return as_bf8(qlds[(hd * NF + ft) * 64]);
+      else return as_bf8(bufld4(rsp, pvoff, (unsigned)(ft * 16 * C::H + hd * C::DH) * 2u));
     };
-#endif
     attention16<C, false>(qf, reinterpret_cast<const __bf16*>(a.kc) + (size_t)b * a.Sp * C::H,
                           reinterpret_cast<const __bf16*>(a.vcT) + (size_t)b * C::H * a.Sp, a.Sp, a.S, -1, m0, lane,
                           [&](int, const bf8 (&ob)[NF]) { ktile16<C::HT>(ring, ob, h); }
@@ -1041,17 +1235,18 @@ __global__ __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) void k_layer16(K
   }
   STAMP16(3);
   // ---- x = x + ffn(norm3(x, cond))   (transformer.py:154-158, :13-49) ----
-  {
+  if (EDTTS16_PHASES & 4) {
     bf8 hn[C::KT][NF];
     rms_norm_pack<C>(h, a.n3w, a.cond + (size_t)b * a.cond_bstride + ((size_t)a.layer * 2 + 1) * 2 * C::H, g, hn);
 #pragma unroll
     for (int nt = 0; nt < C::HT; ++nt) {
       const f4 db = ldg4(a.down_b + 16 * nt + 4 * g);
 #pragma unroll
-      for (int ft = 0; ft < NF; ++ft) h[nt][ft] += db;
+      for (int ft = 0; ft < NF; ++ft) acc_put<PIN>(h[nt][ft], acc_get<PIN>(h[nt][ft]) + db);
     }
     for (int jp = 0; jp < a.ffn_tiles / 2; ++jp) {  // ffn_mult * H hidden features = k-tiles (32 wide) of the down projection
       f4 act[2][NF];
+      f2s half[2][NF];  // (NF = 4: each n-tile's activations are packed as soon as they exist -- 16 registers instead of 32)
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const int j = 2 * jp + u;
@@ -1069,29 +1264,47 @@ __global__ __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) void k_layer16(K
           const f4 d = e + 1.0f;
           const f4 rc = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1]), __builtin_amdgcn_rcpf(d[2]), __builtin_amdgcn_rcpf(d[3])};
           act[u][ft] = (v[ft] * gt[ft]) * rc;  // SwiGLU: value * silu(gate), transformer.py:21-23
+          if constexpr (NF > 2) half[u][ft] = pack4(act[u][ft]);
         }
       }
       bf8 ab[NF];
 #pragma unroll
-      for (int ft = 0; ft < NF; ++ft) ab[ft] = pack8(act[0][ft], act[1][ft]);
+      for (int ft = 0; ft < NF; ++ft) {
+        if constexpr (NF > 2) ab[ft] = as_bf8(f4{half[0][ft][0], half[0][ft][1], half[1][ft][0], half[1][ft][1]});
+        else ab[ft] = pack8(act[0][ft], act[1][ft]);
+      }
       ktile16<C::HT>(ring, ab, h);
     }
   }
   STAMP16(4);
   // ---- tail ----
-  if (TAIL == TAIL_QKV) {
+  // (64-frame waves: the tail's addresses are formed from fresh copies of the tile coordinates -- hipcc otherwise forms them at the top
+  // of the kernel and carries them through every phase in registers it does not have)
+  int lane_t = lane, b_t = b, m0_t = m0;
+  if constexpr (PIN) asm volatile("" : "+v"(lane_t), "+s"(b_t), "+s"(m0_t));
+  const int fq_t = lane_t & 15, g_t = lane_t >> 4;
+  float* const hp_t = a.h + ((size_t)b_t * a.Tp + m0_t + fq_t) * C::H + 4 * g_t;
+  if (!(EDTTS16_PHASES & 8)) {
+    f4 t = splat(0.f);
+#pragma unroll
+    for (int nt = 0; nt < C::HT; ++nt)
+#pragma unroll
+      for (int ft = 0; ft < NF; ++ft) t += acc_get<PIN>(h[nt][ft]);
+    if (valid) stg4(hp_t, t);
+  } else if (TAIL == TAIL_QKV) {
     if (valid) {
+      float* hs = hp_t;
 #pragma unroll
       for (int nt = 0; nt < C::HT; ++nt)
 #pragma unroll
-        for (int ft = 0; ft < NF; ++ft) stg4(hp + 16 * nt + (size_t)ft * 16 * C::H, h[nt][ft]);
+        for (int ft = 0; ft < NF; ++ft) stg4(hs + 16 * nt + (size_t)ft * 16 * C::H, acc_get<PIN>(h[nt][ft]));
     }
     bf8 hn[C::KT][NF];
-    rms_norm_pack<C>(h, a.n1w, a.cond + (size_t)b * a.cond_bstride + ((size_t)(a.layer + 1) * 2) * 2 * C::H, g, hn);
-    qkv_tail16<C>(ring, hn, a, b, m0, lane, valid);
+    rms_norm_pack<C>(h, a.n1w, a.cond + (size_t)b_t * a.cond_bstride + ((size_t)(a.layer + 1) * 2) * 2 * C::H, g_t, hn);
+    qkv_tail16<C>(ring, hn, a, b_t, m0_t, lane_t, valid);
   } else {
     bf8 hn[C::KT][NF];
-    layer_norm_pack<C>(h, a.fnw, a.fnb, g, hn);
+    layer_norm_pack<C>(h, a.fnw, a.fnb, g_t, hn);
     for (int p = 0; p < C::MTP; ++p) {
       f4 e[2][NF];
 #pragma unroll
@@ -1101,12 +1314,12 @@ __global__ __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) void k_layer16(K
       for (int u = 0; u < 2; ++u) {
         const int nt = 2 * p + u;
         if (nt >= C::MT) continue;  // the padding half of the last pair
-        const f4 ob = *reinterpret_cast<const f4*>(params + C::UPB_FLOATS + 16 * nt + 4 * g);
+        const f4 ob = *reinterpret_cast<const f4*>(params + C::UPB_FLOATS + 16 * nt + 4 * g_t);
 #pragma unroll
         for (int ft = 0; ft < NF; ++ft) {
-          const int f = m0 + 16 * ft + fq;
+          const int f = m0_t + 16 * ft + fq_t;
           if (f >= a.T || !valid) continue;
-          tail_apply<TAIL>(a, ((size_t)b * a.T + f) * C::MEL + 16 * nt + 4 * g, e[u][ft] + ob);
+          tail_apply<TAIL>(a, ((size_t)b_t * a.T + f) * C::MEL + 16 * nt + 4 * g_t, e[u][ft] + ob);
         }
       }
     }

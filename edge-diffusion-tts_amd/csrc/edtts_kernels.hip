@@ -1853,6 +1853,17 @@ struct Launcher16 {
   // 32-frame waves would leave half of the SIMDs without one (B * T <= 16 k frames on an MI355X).
   static constexpr bool HAS_SMALL = C::NF == 2 && C::H == 256;
   using Small = edtts16::Cfg16<C::H, C::HEADS, C::MEL, 1>;
+  // The 64-frames-per-wave instance (every weight fragment read from the LDS ring feeds four MFMAs instead of two, every K / V^T
+  // tile four instead of two): measured at config 3 it runs the FFN and tail phases ~28 % faster and the attention ~8 % slower
+  // (one head per step, twice the context working set per XCD) -- 34.25 vs 34.16 ms per call, DESIGN.md 4.5 -- so it is not
+  // selected by default; EDTTS16_WIDE=1 (read once per process) selects it wherever the padded length allows.
+  static constexpr bool HAS_WIDE = C::NF == 2 && C::H == 256;
+  using Wide = edtts16::Cfg16<C::H, C::HEADS, C::MEL, 4>;
+  static bool use_wide(int B, int Tp) {
+    static const bool on = [] { const char* e = getenv("EDTTS16_WIDE"); return e && e[0] == '1'; }();
+    (void)B;
+    return on && Tp % 64 == 0;
+  }
   static int simds() {
     static int n[64] = {};
     int dev = 0;
@@ -1871,6 +1882,10 @@ struct Launcher16 {
     if (done[dev]) return EDTTS_OK;
     if constexpr (HAS_SMALL) {
       int rc = Launcher16<Small>::set_attrs();
+      if (rc) return rc;
+    }
+    if constexpr (HAS_WIDE) {
+      int rc = Launcher16<Wide>::set_attrs();
       if (rc) return rc;
     }
     const int lds = C::LDS_BYTES;
@@ -1929,6 +1944,11 @@ struct Launcher16 {
                      const float* x, const float* cond_row, int cond_bstride, int tail, float* eps, float* x_prev, float* x0,
                      const float* coef, hipStream_t st, const DdpmStep* ddpm = nullptr, const LmsStep* lms = nullptr,
                      const VpredStepArgs* vp = nullptr) {
+    if constexpr (HAS_WIDE) {
+      if (use_wide(B, ws.Tp))
+        return Launcher16<Wide>::forward(lo, blob, ws, wsb, B, T, S, window, x, cond_row, cond_bstride, tail, eps, x_prev, x0, coef, st,
+                                         ddpm, lms, vp);
+    }
     if constexpr (HAS_SMALL) {
       if (2 * B * (ws.Tp / C::WF) <= simds())
         return Launcher16<Small>::forward(lo, blob, ws, wsb, B, T, S, window, x, cond_row, cond_bstride, tail, eps, x_prev, x0, coef, st,

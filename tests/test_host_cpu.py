@@ -254,6 +254,23 @@ def test_no_product_kernel_uses_scratch():
     assert not any(re.search(r"k_layerIN5edtts3CfgI[^E]*EELi\dELi[12]E", k) for k in res), "PART_ATTN / PART_FFN instances in the product build"
 
 
+def test_inline_mfma_hazard_rule():
+    """build() walks the device assembly for instructions that touch the destination registers of an inline-assembly MFMA block
+    (the 64-frame bf16 instance accumulates into AGPRs it names itself, so hipcc's hazard recogniser does not cover them) before
+    the MFMA has left the pipe."""
+    import __graft_entry__ as G
+    block = ("_Z3foo:\n\t;;#ASMSTART\n\ts_nop 1\n\tv_mfma_f32_16x16x32_bf16 a[0:3], v[0:3], v[4:7], a[0:3]\n"
+             "\tv_mfma_f32_16x16x32_bf16 a[4:7], v[0:3], v[8:11], a[4:7]\n\t;;#ASMEND\n")
+    early = block + "\tv_add_f32 v1, v2, v3\n\tv_accvgpr_read_b32 v9, a5\n\ts_endpgm\n"
+    assert G.inline_mfma_hazards(early) == [("_Z3foo", 8, "v_accvgpr_read_b32 v9, a5")]
+    fenced = block + "\ts_nop 15\n\ts_nop 15\n\tv_accvgpr_read_b32 v9, a5\n\ts_endpgm\n"
+    assert G.inline_mfma_hazards(fenced) == []
+    chained = block + "\t;;#ASMSTART\n\tv_mfma_f32_16x16x32_bf16 a[8:11], v[0:3], v[4:7], a[8:11]\n\t;;#ASMEND\n\ts_endpgm\n"
+    assert G.inline_mfma_hazards(chained) == []  # the next block accumulates into other registers
+    clobber = block + "\tv_accvgpr_write_b32 a2, v0\n\ts_endpgm\n"
+    assert len(G.inline_mfma_hazards(clobber)) == 1
+
+
 def test_workspace_cache_evicts_least_recently_used():
     """decoder.workspace(): bounded cache, least-recently-USED entry dropped first (round 2 cleared the whole cache, which could free
     a workspace a captured graph still replays into; those are pinned -- GPU test test_samplers_are_graph_capturable)."""
