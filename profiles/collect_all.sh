@@ -15,6 +15,11 @@ timeout -k 10 200 python3 bench.py --batch 32 --no-pmc --no-cpu-baseline > "$OUT
 timeout -k 10 300 python3 bench.py --config 5 --no-pmc > "$OUT/bench_cfg5.json" 2> "$OUT/bench_cfg5.err"
 timeout -k 10 200 python3 bench.py --config 3 --batch 32 --steps 20 --no-pmc --no-cpu-baseline > "$OUT/bench_cfg3_b32.json" 2> "$OUT/bench_cfg3_b32.err"
 timeout -k 10 200 python3 bench.py --config 3 --batch 16 --steps 30 --no-pmc --no-cpu-baseline > "$OUT/bench_cfg3_b16.json" 2> "$OUT/bench_cfg3_b16.err"
+echo "== config 3, 64-frame bf16 instance (EDTTS16_WIDE=1)"
+export EDTTS16_WIDE=1
+timeout -k 10 300 python3 bench.py --config 3 --no-cpu-baseline > "$OUT/bench_cfg3_bf16_wide.json" 2> "$OUT/bench_cfg3_bf16_wide.err"
+timeout -k 10 600 bash scratch/pmc_cfg3.sh "${TAG}w" > "$OUT/pmc_cfg3_wide.log" 2>&1
+unset EDTTS16_WIDE
 echo "== elementwise"; timeout -k 10 200 python3 scratch/bench_elementwise.py 2>/dev/null > "$OUT/elementwise.json"
 echo "== ring probe"; timeout -k 5 60 scratch/ring_probe > "$OUT/ring_probe.txt" 2>&1
 ls -la "$OUT"
