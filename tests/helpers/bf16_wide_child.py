@@ -31,4 +31,24 @@ x = torch.randn(B, 2 * S, 80, generator=gen).to(DEV)
 big = infer.generate_mel(sem, 4, x_T=x)
 again = infer.generate_mel(sem, 4, x_T=x)
 alone = torch.cat([infer.generate_mel(sem[i:i + 1].contiguous(), 4, x_T=x[i:i + 1].contiguous()) for i in (0, 11, 23)])
-np.savez(out, eps=eps.numpy(), big=big.cpu().numpy(), again=again.cpu().numpy(), alone=alone.cpu().numpy())
+# ragged geometries against the CPU oracle (two layers of the same width): padded frame tiles (T = 250 -> 256), a partial last
+# key chunk, windows below / on / above the 64-frame group, full attention, a context longer than the utterance
+from oracle import edtts_oracle as O  # noqa: E402
+
+geo = []
+for B2, T2, S2, window in [(2, 250, 100, 16), (1, 128, 33, None), (2, 320, 64, 128), (1, 64, 512, 64), (3, 192, 77, 40)]:
+    cfg2 = CFG(hidden=256, heads=8, layers=2, attn_window_size=window, device=DEV)
+    sd = synth_state_dict(cfg2, 5)
+    d2 = EdgeDiffusionDecoder(cfg2, compute_dtype="bf16")
+    d2.load_state_dict(sd)
+    d2 = d2.to(DEV).eval()
+    g2 = torch.Generator().manual_seed(1000 + T2)
+    x2 = torch.randn(B2, T2, 80, generator=g2)
+    sem2 = torch.randint(0, 512, (B2, S2), generator=g2)
+    t2 = torch.randint(0, 1000, (B2,), generator=g2)
+    si2 = torch.randint(0, 16, (B2,), generator=g2)
+    e2 = d2(x2.to(DEV), t2.to(DEV), sem2.to(DEV), si2.to(DEV)).cpu()
+    ref2 = O.decoder_forward(sd, x2, t2, sem2, si2, heads=8, window=window)
+    dd = (e2.double() - ref2.double())
+    geo.append([T2, S2, -1 if window is None else window, float(dd.pow(2).mean().sqrt()), float(dd.abs().max()), float(torch.isfinite(e2).all())])
+np.savez(out, eps=eps.numpy(), big=big.cpu().numpy(), again=again.cpu().numpy(), alone=alone.cpu().numpy(), geo=np.array(geo))
