@@ -116,6 +116,28 @@ EDTTS_DEV bf8 ldg_bf8(const __bf16* base, unsigned byte_off) {
   return *reinterpret_cast<const bf8*>(reinterpret_cast<const char*>(base) + byte_off);
 }
 
+// Private images.  The residual tile h (fp32) and the q rows (bf16) of a wave's frames are written and read back only by the wave
+// that owns those frames, lane for lane -- so inside the tile's span of the buffer they are stored as the REGISTER IMAGE,
+// [n-tile | head][frame tile][lane] x 16 bytes: every access of a wave is one contiguous KiB instead of 16 row segments of 64 B.
+// (EDTTS16_IMG 0: row-major [frame][H], as the fp32 kernels keep them.)  tile0 = ((b * Tp + m0) * H: the span starts where the
+// row-major rows of the tile would.
+#ifndef EDTTS16_IMG
+#define EDTTS16_IMG 1
+#endif
+template <class C>
+EDTTS_DEV size_t h_at(size_t tile0, int lane, int nt, int ft) {  // floats
+  if (EDTTS16_IMG) return tile0 + (size_t)(nt * C::NF + ft) * 256 + lane * 4;
+  return tile0 + (size_t)((lane & 15) + 16 * ft) * C::H + 16 * nt + 4 * (lane >> 4);
+}
+template <class C>
+EDTTS_DEV size_t q_at(size_t tile0, int lane, int hd, int ft) {  // bf16 elements
+  if (EDTTS16_IMG) return tile0 + (size_t)(hd * C::NF + ft) * 512 + lane * 8;
+  return tile0 + (size_t)((lane & 15) + 16 * ft) * C::H + hd * C::DH + 8 * (lane >> 4);
+}
+// (the same as a per-lane byte offset + a wave-uniform byte offset, for buffer loads / stores from the tile's base)
+template <class C> EDTTS_DEV unsigned q_voff(int lane) { return EDTTS16_IMG ? lane * 16u : (unsigned)((lane & 15) * C::H + 8 * (lane >> 4)) * 2u; }
+template <class C> EDTTS_DEV unsigned q_soff(int hd, int ft) { return EDTTS16_IMG ? (unsigned)(hd * C::NF + ft) * 1024u : (unsigned)(ft * 16 * C::H + hd * C::DH) * 2u; }
+
 // 64-frame waves (NF = 4) keep the residual tile in the 256 AGPRs: it is written by the MFMAs of ktile16 (which name the class
 // themselves) and by acc_put, and read by the VALU through acc_get -- an opaque read, so that hipcc cannot keep a second, VGPR copy
 // of the tile alive from one reader to the next (it did: 460 spilled registers).  NF <= 2: plain values.
@@ -745,9 +767,14 @@ EDTTS_DEV void attention16(QF&& qf, const __bf16* __restrict__ Kb, const __bf16*
     // unconditional step pairs plus a tail step, a fourth copy of the step: 53.6 ms, 202 spilled registers.)
     step(true, chunk_of(0), chunk_of(KD), KA0, VA0);
 #ifndef EDTTS16_EVEN_STEPS
-#define EDTTS16_EVEN_STEPS 1
+#define EDTTS16_EVEN_STEPS 1   // 1: padded step groups for the 16- and 32-frame instances; 0: never; 2: always
 #endif
-    if constexpr (KD == 3) {  // (three steps per iteration; steps past the end run fully masked)
+    // (64-frame waves: a step is twice the work, and the interior self-attention walks 6 chunks = 1 + 5 steps -- the masked
+    // padding step costs more than the exact waits gain: 33.5 vs 34.2 ms per call with the last steps behind their conditions)
+    constexpr bool EVEN = EDTTS16_EVEN_STEPS == 2 || (EDTTS16_EVEN_STEPS == 1 && NF <= 2);
+    if constexpr (KD == 3) {
+      // three steps per iteration, always padded: with these steps behind conditions the 16-step cross-attention loses what the
+      // third buffer set gained (35.1 vs 33.5 ms per call: the waits are no longer exact)
       for (int st = 1; st < nchunk; st += 3) {
         step(false, chunk_of(st), chunk_of(st + 3), KA1, VA1);
         step(false, st + 1 < nchunk ? chunk_of(st + 1) : -1, chunk_of(st + 4), KA2, VA2);
@@ -756,12 +783,9 @@ EDTTS_DEV void attention16(QF&& qf, const __bf16* __restrict__ Kb, const __bf16*
     } else
     for (int st = 1; st < nchunk; st += 2) {
       step(false, chunk_of(st), chunk_of(st + 2), KA1, VA1);
-#if EDTTS16_EVEN_STEPS
-      // always two steps per iteration (no branch around a load): a step past the end runs fully masked
-      step(false, st + 1 < nchunk ? chunk_of(st + 1) : -1, chunk_of(st + 3), KA0, VA0);
-#else
-      if (st + 1 < nchunk) step(false, chunk_of(st + 1), chunk_of(st + 3), KA0, VA0);
-#endif
+      // EVEN: always two steps per iteration (no branch around a load): a step past the end runs fully masked
+      if constexpr (EVEN) step(false, st + 1 < nchunk ? chunk_of(st + 1) : -1, chunk_of(st + 3), KA0, VA0);
+      else if (st + 1 < nchunk) step(false, chunk_of(st + 1), chunk_of(st + 3), KA0, VA0);
     }
     bf8 ob[HP][NF];
 #pragma unroll
@@ -957,15 +981,15 @@ EDTTS_DEV void qkv_tail16(Ring16<C>& ring, const bf8 (&hn)[C::KT][C::NF], const 
 #pragma unroll
       for (int ft = 0; ft < NF; ++ft) acc[0][ft] = acc[1][ft] = splat(0.f);
       gemm16_pair<C::KT, false>(ring, hn, acc[0], acc[1]);
-      // q: row-major [frame][H] (read back by this wave only); k: tile-contiguous image [head p][key tile][16 keys][32 slots].
+      // q: the wave's private image (q_at; read back by this wave only); k: tile-contiguous image [head p][key tile][16 keys][32 slots].
       // PLAIN stores, not streaming ones: on gfx9 stores retire through the same in-order vmcnt as the ring's DMAs, and a
       // nontemporal store takes microseconds to be acknowledged -- scratch/ring_probe.cpp: 9 060 vs 1 920 cycles per phase.
       // (Measured and dropped: the residual tile's 32 stores spread over the q phases instead of one burst in front of the tail,
       // with and without an allowance for the known younger stores in the ring's counted vmcnt waits -- 38.6 - 38.9 ms either way;
       // skipping the q / k / v^T stores altogether: 36.8 ms.)
-      __bf16* dst = which == 0 ? qo + rowbase * C::H + 32 * p + 8 * g
+      __bf16* dst = which == 0 ? qo + q_at<C>(((size_t)b * a.Tp + m0) * C::H, lane, p, 0)
                                : ko + ((size_t)(b * C::HEADS + p) * (a.Tp >> 4) + (m0 >> 4)) * 512 + fq * 32 + 8 * g;
-      const size_t fstride = which == 0 ? (size_t)16 * C::H : 512;
+      const size_t fstride = which == 0 ? q_at<C>(0, 0, 0, 1) : 512;
       if (valid)
 #pragma unroll
       for (int ft = 0; ft < NF; ++ft)
@@ -1038,11 +1062,11 @@ __global__ __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) void k_prologue1
       acc_put<(NF > 2)>(h[nt][ft], acc_get<(NF > 2)>(h[nt][ft]) + ldg4(a.pe + (size_t)f * C::H + 16 * nt + 4 * g));
   }
   if (valid) {
-    float* hp = a.h + ((size_t)b * a.Tp + m0 + fq) * C::H + 4 * g;
+    const size_t tile0 = ((size_t)b * a.Tp + m0) * C::H;
 #pragma unroll
     for (int nt = 0; nt < C::HT; ++nt)
 #pragma unroll
-      for (int ft = 0; ft < NF; ++ft) stg4(hp + 16 * nt + (size_t)ft * 16 * C::H, acc_get<(NF > 2)>(h[nt][ft]));
+      for (int ft = 0; ft < NF; ++ft) stg4(a.h + h_at<C>(tile0, lane, nt, ft), acc_get<(NF > 2)>(h[nt][ft]));
   }
   bf8 hn[C::KT][NF];
   rms_norm_pack<C>(h, a.n1w, a.cond + (size_t)b * a.cond_bstride, g, hn);
@@ -1069,9 +1093,9 @@ __global__ __launch_bounds__(C::THREADS, EDTTS16_ATT_OCC) void k_attn16(KArgs a)
   const int lane = threadIdx.x & 63, fq = lane & 15, g = lane >> 4;
   const int b = tl.b, m0 = tl.m0;
   const size_t rowbase = (size_t)b * a.Tp + m0 + fq;
-  const __bf16* qrow = reinterpret_cast<const __bf16*>(a.attn_q) + rowbase * C::H + 8 * g;
+  const __bf16* qbase = reinterpret_cast<const __bf16*>(a.attn_q);
   __bf16* orow = reinterpret_cast<__bf16*>(a.attn_o) + rowbase * C::H + 8 * g;
-  auto qf = [&](int hd, int ft) { return *reinterpret_cast<const bf8*>(qrow + (size_t)ft * 16 * C::H + hd * C::DH); };
+  auto qf = [&](int hd, int ft) { return *reinterpret_cast<const bf8*>(qbase + q_at<C>(((size_t)b * a.Tp + m0) * C::H, lane, hd, ft)); };
   auto sink = [&](int hd, const bf8 (&ob)[NF]) {
 #pragma unroll
     for (int ft = 0; ft < NF; ++ft) *reinterpret_cast<bf8*>(orow + (size_t)ft * 16 * C::H + hd * C::DH) = ob[ft];
@@ -1122,12 +1146,12 @@ __global__ __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) void k_layer16(K
   constexpr int NF = C::NF;
   constexpr bool PIN = NF > 2;  // (64-frame waves: the tile lives in the AGPRs, see acc_get)
   f4 h[C::HT][NF];
-  float* const hp = a.h + rowbase * C::H + 4 * g;
+  const size_t tile0 = ((size_t)b * a.Tp + m0) * C::H;  // the tile's span of the h / q buffers (private images: h_at, q_at)
 #pragma unroll
   for (int nt = 0; nt < C::HT; ++nt) {
     const f4 pb = PART == PART16_POST ? splat(0.f) : ldg4(a.proj_b + 16 * nt + 4 * g);
 #pragma unroll
-    for (int ft = 0; ft < NF; ++ft) acc_put<PIN>(h[nt][ft], ldg4(hp + 16 * nt + (size_t)ft * 16 * C::H) + pb);
+    for (int ft = 0; ft < NF; ++ft) acc_put<PIN>(h[nt][ft], ldg4(a.h + h_at<C>(tile0, lane, nt, ft)) + pb);
   }
   // split layer: this wave's attention output rows (all heads), fetched and WAITED FOR before the streaming loop (a global load
   // consumed inside it would make hipcc drain the ring with vmcnt(0) every phase), then projected head by head
@@ -1151,13 +1175,13 @@ __global__ __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) void k_layer16(K
   // ---- x = x + attn(norm1(x, cond))   (transformer.py:142-146; q / k / v^T were produced by the previous kernel) ----
   if (PART == PART16_MID) project_attn_rows();
   if (PART == PART16_ALL && (EDTTS16_PHASES & 1)) {
-    const __bf16* qrow = reinterpret_cast<const __bf16*>(a.q) + rowbase * C::H + 8 * g;
+    const __bf16* qbase = reinterpret_cast<const __bf16*>(a.q);
     // (64-frame waves: descriptor + scalar offset -- four row pointers held across the head loop were spilled and reloaded per head)
-    const __amdgpu_buffer_rsrc_t rsq = make_rsrc(reinterpret_cast<const __bf16*>(a.q) + ((size_t)b * a.Tp + m0) * C::H);
-    const unsigned qvoff = (unsigned)(fq * C::H + 8 * g) * 2u;
+    const __amdgpu_buffer_rsrc_t rsq = make_rsrc(qbase + tile0);
+    const unsigned qvoff = q_voff<C>(lane);
     auto qf = [&](int hd, int ft) {
-      if constexpr (PIN) return as_bf8(bufld4(rsq, qvoff, (unsigned)(ft * 16 * C::H + hd * C::DH) * 2u));
-      else return *reinterpret_cast<const bf8*>(qrow + (size_t)ft * 16 * C::H + hd * C::DH);
+      if constexpr (PIN) return as_bf8(bufld4(rsq, qvoff, q_soff<C>(hd, ft)));
+      else return *reinterpret_cast<const bf8*>(qbase + q_at<C>(tile0, lane, hd, ft));
     };
     attention16<C, true>(qf, reinterpret_cast<const __bf16*>(a.k) + (size_t)b * a.Tp * C::H,
                          reinterpret_cast<const __bf16*>(a.vT) + (size_t)b * C::H * a.Tp, a.Tp, a.T, a.window, m0, lane,
@@ -1174,7 +1198,7 @@ __global__ __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) void k_layer16(K
     // cross q of this wave's rows -> memory, residual -> memory; the cross-attention kernel and PART16_POST take over
     bf8 hn[C::KT][NF];
     rms_norm_pack<C>(h, a.n2w, nullptr, g, hn);
-    __bf16* qrow = reinterpret_cast<__bf16*>(a.qc_out) + rowbase * C::H + 8 * g;
+    __bf16* qcb = reinterpret_cast<__bf16*>(a.qc_out);
     for (int p = 0; p < C::KT; ++p) {
       f4 acc[2][NF];
 #pragma unroll
@@ -1182,13 +1206,13 @@ __global__ __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) void k_layer16(K
       gemm16_pair<C::KT, false>(ring, hn, acc[0], acc[1]);
       if (valid)
 #pragma unroll
-        for (int ft = 0; ft < NF; ++ft) *reinterpret_cast<f4*>(qrow + (size_t)ft * 16 * C::H + p * C::DH) = as_f4(pack8(acc[0][ft], acc[1][ft]));
+        for (int ft = 0; ft < NF; ++ft) *reinterpret_cast<f4*>(qcb + q_at<C>(tile0, lane, p, ft)) = as_f4(pack8(acc[0][ft], acc[1][ft]));
     }
     if (valid) {
 #pragma unroll
       for (int nt = 0; nt < C::HT; ++nt)
 #pragma unroll
-        for (int ft = 0; ft < NF; ++ft) stg4(hp + 16 * nt + (size_t)ft * 16 * C::H, h[nt][ft]);
+        for (int ft = 0; ft < NF; ++ft) stg4(a.h + h_at<C>(tile0, lane, nt, ft), h[nt][ft]);
     }
     ring.drain();
     return;
@@ -1199,8 +1223,8 @@ __global__ __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) void k_layer16(K
     // its self-attention has finished with (no other wave reads q rows; a padding wave stores nothing and reads what it finds).
     f4* const qlds = ring_lds16 + C::NS * C::PH * 64 + (C::PARAM_FLOATS + 3) / 4 +
                      (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * C::HEADS * NF) * 64 + lane;
-    const __amdgpu_buffer_rsrc_t rsp = make_rsrc(reinterpret_cast<const __bf16*>(a.q) + ((size_t)b * a.Tp + m0) * C::H);
-    const unsigned pvoff = (unsigned)(fq * C::H + 8 * g) * 2u;
+    const __amdgpu_buffer_rsrc_t rsp = make_rsrc(reinterpret_cast<const __bf16*>(a.q) + tile0);
+    const unsigned pvoff = q_voff<C>(lane);
     {
       bf8 hn[C::KT][NF];
       rms_norm_pack<C>(h, a.n2w, nullptr, g, hn);
@@ -1214,7 +1238,7 @@ __global__ __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) void k_layer16(K
           if constexpr (C::QLDS) qlds[(p * NF + ft) * 64] = as_f4(pack8(acc[0][ft], acc[1][ft]));
           else if (valid)
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, pack8(acc[0][ft], acc[1][ft])),
-                                                   rsp, pvoff, (unsigned)(ft * 16 * C::H + p * C::DH) * 2u, 0);
+                                                   rsp, pvoff, q_soff<C>(p, ft), 0);
         }
       }
     }
@@ -1223,7 +1247,7 @@ __global__ __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) void k_layer16(K
     STAMP16(2);
     auto qf = [&](int hd, int ft) {
       if constexpr (C::QLDS) return as_bf8(qlds[(hd * NF + ft) * 64]);
-      else return as_bf8(bufld4(rsp, pvoff, (unsigned)(ft * 16 * C::H + hd * C::DH) * 2u));
+      else return as_bf8(bufld4(rsp, pvoff, q_soff<C>(hd, ft)));
     };
     attention16<C, false>(qf, reinterpret_cast<const __bf16*>(a.kc) + (size_t)b * a.Sp * C::H,
                           reinterpret_cast<const __bf16*>(a.vcT) + (size_t)b * C::H * a.Sp, a.Sp, a.S, -1, m0, lane,
@@ -1283,21 +1307,20 @@ __global__ __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) void k_layer16(K
   int lane_t = lane, b_t = b, m0_t = m0;
   if constexpr (PIN) asm volatile("" : "+v"(lane_t), "+s"(b_t), "+s"(m0_t));
   const int fq_t = lane_t & 15, g_t = lane_t >> 4;
-  float* const hp_t = a.h + ((size_t)b_t * a.Tp + m0_t + fq_t) * C::H + 4 * g_t;
+  const size_t tile0_t = ((size_t)b_t * a.Tp + m0_t) * C::H;
   if (!(EDTTS16_PHASES & 8)) {
     f4 t = splat(0.f);
 #pragma unroll
     for (int nt = 0; nt < C::HT; ++nt)
 #pragma unroll
       for (int ft = 0; ft < NF; ++ft) t += acc_get<PIN>(h[nt][ft]);
-    if (valid) stg4(hp_t, t);
+    if (valid) stg4(a.h + h_at<C>(tile0_t, lane_t, 0, 0), t);
   } else if (TAIL == TAIL_QKV) {
     if (valid) {
-      float* hs = hp_t;
 #pragma unroll
       for (int nt = 0; nt < C::HT; ++nt)
 #pragma unroll
-        for (int ft = 0; ft < NF; ++ft) stg4(hs + 16 * nt + (size_t)ft * 16 * C::H, acc_get<PIN>(h[nt][ft]));
+        for (int ft = 0; ft < NF; ++ft) stg4(a.h + h_at<C>(tile0_t, lane_t, nt, ft), acc_get<PIN>(h[nt][ft]));
     }
     bf8 hn[C::KT][NF];
     rms_norm_pack<C>(h, a.n1w, a.cond + (size_t)b_t * a.cond_bstride + ((size_t)(a.layer + 1) * 2) * 2 * C::H, g_t, hn);

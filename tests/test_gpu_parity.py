@@ -1015,7 +1015,9 @@ def test_bf16_wide_instance(golden, tmp_path):
     cfg, dec = _cfg3_bf16()
     e_def = dec(cu(g["x_t"]), cu(g["t"]), cu(g["sem_idx"]), cu(g["step_idx"])).cpu()
     assert rms(w["eps"], g["eps"]) < BF16_RMS_TOL and max_abs(w["eps"], g["eps"]) < BF16_MAX_TOL
-    assert rms(w["eps"], g["eps"]) <= rms(e_def, g["eps"]) * 1.05 and not torch.equal(w["eps"], e_def)  # (another instance did run)
+    assert rms(w["eps"], g["eps"]) <= rms(e_def, g["eps"]) * 1.05
+    if os.environ.get("EDTTS16_WIDE") != "1":  # (unless this process runs the 64-frame instance itself)
+        assert not torch.equal(w["eps"], e_def), "the child did not run another instance" 
     assert torch.equal(w["big"], w["again"]) and torch.equal(w["alone"], w["big"][[0, 11, 23]])
     for T2, S2, win, e_rms, e_max, finite in w["geo"].tolist():  # ragged geometries against the CPU oracle (see the child)
         print(f"wide instance, T={int(T2)} S={int(S2)} window={int(win)}: rms {e_rms:.2e} max {e_max:.2e}")
