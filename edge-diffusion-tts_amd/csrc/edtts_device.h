@@ -23,7 +23,7 @@
                                     (defined(EDTTS_KV2) && EDTTS_KV2) || (defined(EDTTS_PERSIST) && EDTTS_PERSIST) || \
                                     (defined(EDTTS_H_DMA) && EDTTS_H_DMA) || (defined(EDTTS_SPLITLOAD) && !EDTTS_SPLITLOAD) || \
                                     defined(EDTTS_STAMPS) || defined(EDTTS16_ABLATE_BARRIER) || defined(EDTTS16_ABLATE_DMA) || \
-                                    (defined(EDTTS16_SPLIT_BUILD) && EDTTS16_SPLIT_BUILD) || (defined(EDTTS16_PHASES) && EDTTS16_PHASES != 15))
+                                    (defined(EDTTS16_SPLIT_BUILD) && EDTTS16_SPLIT_BUILD) || (defined(EDTTS16_PHASES) && EDTTS16_PHASES != 15) || (defined(EDTTS_DS_ABL) && EDTTS_DS_ABL))
 #error "ablation / diagnostic / measured-and-rejected variant switches are scratch-only: add -DEDTTS_EXPERIMENTS"
 #endif
 

@@ -1397,7 +1397,7 @@ __global__ __launch_bounds__(128) void k_dsconv_norm(const float* __restrict__ z
 // T_out <= 128 NP.
 // ---------------------------------------------------------------------------------------------------------
 constexpr int kDfT = 128, kDfWaves = kDfT / 16, kDfThreads = 64 * kDfWaves;
-constexpr int kDfXld = 264;  // raw input frames per pass and channel: 127 * stride + ksize <= 260 (+ padding against bank conflicts)
+constexpr int kDfXld = 260;  // raw input frames per pass and channel: 127 * stride + ksize <= 260; 4 rows apart = 16 banks apart: the four lane groups of a depthwise read (rows 4 g + r) fall on disjoint banks
 template <int KT, int CT>
 constexpr int dsconv_fused_lds_floats() { return 16 * CT * (16 * KT + 4) + 16 * KT * kDfXld; }
 // erf(x) by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7 absolute, far inside the layer's 1e-5 budget): 1 rcp + 1 exp2 + 7 VALU
@@ -1413,6 +1413,9 @@ EDTTS_DEV float erf_as(float x) {
   const float r = fmaf(-p * t, e, 1.0f);
   return copysignf(r, x);
 }
+#ifndef EDTTS_DS_ABL
+#define EDTTS_DS_ABL 0   // timing ablations (-DEDTTS_EXPERIMENTS; results wrong): 1 no erf, 2 no stores, 4 no MFMAs, 8 no input staging, 16 no statistics
+#endif
 template <int KT, int CT, int NP>
 __global__ __launch_bounds__(kDfThreads) void k_dsconv_fused(const float* __restrict__ x, const float* __restrict__ dw, const float* __restrict__ pw,
                                                              const float* __restrict__ pb, const float* __restrict__ gw, const float* __restrict__ gb,
@@ -1451,7 +1454,7 @@ __global__ __launch_bounds__(kDfThreads) void k_dsconv_fused(const float* __rest
 #pragma unroll
           for (int u = 0; u < SEG; ++u) {
             const int tl = lane + 64 * u, ts = t0 + tl;
-            v[h][u] = (ci < Ci && tl < nin && ts >= 0 && ts < T) ? xr[ts] : 0.f;
+            v[h][u] = ((EDTTS_DS_ABL & 8) == 0 && ci < Ci && tl < nin && ts >= 0 && ts < T) ? xr[ts] : 0.f;
           }
         }
 #pragma unroll
@@ -1468,16 +1471,19 @@ __global__ __launch_bounds__(kDfThreads) void k_dsconv_fused(const float* __rest
     __syncthreads();  // (also covers the weight tile on the first pass)
     f4 at[KT];  // A operand = depthwise output: rows = this wave's 16 frames (lane fq), k = input channel 16 kt + 4 g + r
 #pragma unroll
-    for (int kt = 0; kt < KT; ++kt)
+    for (int kt = 0; kt < KT; ++kt) at[kt] = splat(0.f);
+    // Conv1d(stride, padding = k/2), layers/conv.py:33-41 (rows >= Ci are zero).  The tap loop is the OUTER one: its trip count is
+    // a run-time value, and with it innermost the 4 KT channel sums were 4 KT separate little loops, each a serial chain of
+    // LDS + global latencies (40 % of the kernel's time); a tap now issues 4 KT independent load pairs.  Same sums, tap by tap.
+    for (int j = 0; j < ks; ++j) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int ci = 16 * kt + 4 * g + r;
-        const float* xr = xs + ci * kDfXld + (16 * wave + fq) * stride;
-        const float* wj = dw + (ci < Ci ? ci : 0) * ks;
-        float d = 0.f;
-        for (int j = 0; j < ks; ++j) d = fmaf(xr[j], wj[j], d);  // Conv1d(stride, padding = k/2), layers/conv.py:33-41 (rows >= Ci are zero)
-        at[kt][r] = d;
-      }
+      for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int ci = 16 * kt + 4 * g + r;
+          at[kt][r] = fmaf(xs[ci * kDfXld + (16 * wave + fq) * stride + j], dw[(ci < Ci ? ci : 0) * ks + j], at[kt][r]);
+        }
+    }
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
       if (16 * ct >= Co) break;  // (uniform)
@@ -1485,7 +1491,10 @@ __global__ __launch_bounds__(kDfThreads) void k_dsconv_fused(const float* __rest
       for (int kt = 0; kt < KT; ++kt) {
         const f4 w = *reinterpret_cast<const f4*>(wsm + (16 * ct + fq) * WLD + 16 * kt + 4 * g);  // B operand: column = channel 16 ct + fq
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[ct][p] = EDTTS_MFMA(at[kt][r], w[r], acc[ct][p]);
+        for (int r = 0; r < 4; ++r) {
+          if (EDTTS_DS_ABL & 4) acc[ct][p][r] += at[kt][r] * w[r];
+          else acc[ct][p] = EDTTS_MFMA(at[kt][r], w[r], acc[ct][p]);
+        }
       }
     }
   }
@@ -1538,8 +1547,14 @@ __global__ __launch_bounds__(kDfThreads) void k_dsconv_fused(const float* __rest
     }
     __syncthreads();
   };
-  channel_reduce(false);
-  channel_reduce(true);
+  if (EDTTS_DS_ABL & 16) {
+    __syncthreads();
+    if (threadIdx.x < 2 * groups) gst[threadIdx.x] = (threadIdx.x & 1) ? 1.f : 0.f;
+    __syncthreads();
+  } else {
+    channel_reduce(false);
+    channel_reduce(true);
+  }
   // ---- y = GELU(GroupNorm(z)): 16-byte stores where the row allows it ----
   const bool vec = (To & 3) == 0;
 #pragma unroll
@@ -1555,8 +1570,9 @@ __global__ __launch_bounds__(kDfThreads) void k_dsconv_fused(const float* __rest
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float v = (acc[ct][p][r] - mu) * rs * w + bb;
-        o[r] = 0.5f * v * (1.0f + erf_as(v * 0.70710678118654752440f));
+        o[r] = (EDTTS_DS_ABL & 1) ? v : 0.5f * v * (1.0f + erf_as(v * 0.70710678118654752440f));
       }
+      if ((EDTTS_DS_ABL & 2) && o[0] != 12345.f) continue;
       if (vec && t0 + 3 < To) stg4(yr + t0, o);
       else {
 #pragma unroll
