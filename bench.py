@@ -160,6 +160,8 @@ def main():
     ap.add_argument("--dtype", default=None, choices=("f32", "bf16"))
     ap.add_argument("--batch", type=int, default=None, help="utterances per GPU (default: the config's)")
     ap.add_argument("--frames", type=int, default=None, help="mel frames per utterance (T = 2*S)")
+    ap.add_argument("--substreams", type=int, default=None, choices=(1, 2, 3, 4),
+                    help="sub-batches of a sampler call on two streams (include/edtts.h: edtts_set_substreams); default: the library's (2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -249,6 +251,14 @@ def main():
         sch = DiffusionSchedule(cfg.diff_steps).to(dev)
         infer = EdgeInference(cfg, sch, torch.nn.Identity(), dec)
 
+    if not stub:
+        if args.pmc_child:
+            native.set_substreams(1)  # counters per k_layer launch: launches must not share the device
+        elif args.substreams is not None:
+            native.set_substreams(args.substreams)
+        substreams = native.set_substreams(0)  # (0 only queries)
+    else:
+        substreams = 1
     if C["sampler"] == "ddpm":
         # BASELINE config 5: the whole 1000-step ancestral sampler captured ONCE as a hipGraph; a step = one replay.  The start
         # noise is drawn into the graph's static input buffer inside the timed step.
@@ -347,6 +357,7 @@ def main():
         "config": {"workload": f"BASELINE config {args.config}: {what}, decoder hidden={H} L={L} heads={cfg.heads} n_mels={M} window={W}, "
                                f"B={B}/GPU T={T} S={S}, synthetic weights + tokens, start noise drawn inside the timed call",
                    "batch_per_gpu": B, "frames": T, "sampler_steps": C["num_steps"],
+                   "substreams": substreams,  # 2: batches of >= 2 rounds of waves run as two half-batches on two streams (edtts.h)
                    "parallelism": (f"batch-sharded x{world}, all-gather of the final mel batch" + (f" overlapped with compute in {micro} slices" if micro > 1 else ""))
                    if world > 1 else "single GPU"},
         "mels_per_s": world * B / (dt / steps),
@@ -374,6 +385,9 @@ def main():
         per_call = C["num_steps"] * L
         if C["sampler"] == "ddpm":
             n_prof, per_call = 1, C["num_steps"] * L
+        # the kernel is timed ALONE on the device (as rocprofv3's kernel trace of profiles/ sees it with EDTTS_SUBSTREAMS=1): with the
+        # two-stream cut of the headline loop two launches share the SIMDs and a launch's own duration says nothing about its rate
+        native.set_substreams(1)
         native.profile_enable(n_prof * per_call)
         for _ in range(n_prof):
             if C["sampler"] == "ddpm":
@@ -383,6 +397,7 @@ def main():
         torch.cuda.synchronize(dev)
         (ms0, n0), (ms1, n1) = native.profile_collect()
         native.profile_enable(0)
+        native.set_substreams(substreams)
         frames = B * T
         fl_layer = frames * sum(layer_flops_per_frame(H, M, S, T, W, l == L - 1) for l in range(L)) / L  # mean over the L launches
         avg = (ms0 + ms1) / max(n0, 1)
@@ -394,6 +409,7 @@ def main():
             "traffic": traffic["bytes"] if traffic else None, "traffic_read": traffic["read"] if traffic else None,
             "traffic_write": traffic["write"] if traffic else None, "traffic_source": traffic_src,
             "layer_kernels_share_of_step": avg * per_call / median_ms if C["sampler"] == "ddim" else None,
+            "launch_mode": "one launch at a time (edtts_set_substreams(1)); the headline loop ran with substreams=%d" % substreams,
         }
         if traffic:
             gbs = traffic["bytes"] / (avg * 1e-3) / 1e9

@@ -27,6 +27,14 @@
 #error "ablation / diagnostic / measured-and-rejected variant switches are scratch-only: add -DEDTTS_EXPERIMENTS"
 #endif
 
+#ifndef EDTTS_W2
+#define EDTTS_W2 0  // experiment: the 32-frame instances at two waves per SIMD (<= 256 registers, no AGPR-class pins)
+#endif
+#if EDTTS_W2
+#define EDTTS_PIN_ACC(x) asm volatile("" : "+v"(x))
+#else
+#define EDTTS_PIN_ACC(x) asm volatile("" : "+a"(x))
+#endif
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef float f2 __attribute__((ext_vector_type(2)));
 
@@ -80,7 +88,7 @@ struct Cfg {
   static constexpr int WAVES = NF == 1 ? 1 : (WAVES0 < EDTTS_WMAX ? WAVES0 : EDTTS_WMAX);
   // the cross-attention q tile goes through LDS when it fits next to the parked residual tiles (160 KiB per block at H = 160,
   // NF = 2), else through this wave's (already consumed) self-attention q rows in global memory
-  static constexpr bool Q_IN_LDS = WF * H * 4 * 2 <= 40 * 1024;  // per wave: a quarter of the CU's 160 KiB (four waves per CU, in 1, 2 or 4 blocks)
+  static constexpr bool Q_IN_LDS = !(EDTTS_W2 && NF == 2) && WF * H * 4 * 2 <= 40 * 1024;  // per wave: a quarter of the CU's 160 KiB (four waves per CU, in 1, 2 or 4 blocks)
   static constexpr int THREADS = 64 * WAVES;
   static_assert(NF == 1 || NF == 2 || NF == 4, "frame tiles per wave");
   static_assert(H % 32 == 0 && MEL % 16 == 0 && H % HEADS == 0, "dims");
@@ -371,7 +379,7 @@ EDTTS_DEV float silu(float g) { return g * __builtin_amdgcn_rcpf(1.0f + __expf(-
 // ring the QKV-tail instance spilled (76 B/lane of scratch); 8 fragments = 64 MFMAs of prefetch distance.
 template <class C> constexpr int wstream_ring() {
   constexpr int full = ((C::HT * 2) / C::NF >= 2 && C::HT % ((C::HT * 2) / C::NF) == 0) ? (C::HT * 2) / C::NF : C::HT;
-  return (C::HT >= 16 && full % 2 == 0) ? full / 2 : full;
+  return ((C::HT >= 16 || (EDTTS_W2 && C::NF == 2)) && full % 2 == 0) ? full / 2 : full;
 }
 template <class C> using WStream = FragRing<wstream_ring<C>()>;
 
@@ -383,9 +391,13 @@ EDTTS_DEV void scale_acc(f4& o, float alpha) {
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     float x = o[r], t;
+#if EDTTS_W2
+    asm volatile("s_nop 15\n\tv_mul_f32 %0, %0, %2\n\ts_nop 3" : "+v"(x), "=&v"(t) : "v"(alpha));
+#else
     asm volatile("s_nop 15\n\tv_accvgpr_read_b32 %1, %0\n\ts_nop 1\n\tv_mul_f32 %1, %1, %2\n\ts_nop 1\n\tv_accvgpr_write_b32 %0, %1\n\ts_nop 3"
                  : "+a"(x), "=&v"(t)
                  : "v"(alpha));
+#endif
     o[r] = x;
   }
 }
@@ -766,7 +778,7 @@ EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, cons
             const float m = gm > -1e30f ? gm : 0.f;
             nm[ft] = -m;
             NM[ft] = splat(-m);
-            asm volatile("" : "+a"(NM[ft]));  // the -m tile lives in AGPRs: it is an accumulator input and nothing else
+            EDTTS_PIN_ACC(NM[ft]);  // the -m tile lives in AGPRs: it is an accumulator input and nothing else
             exp_and_sum(ft, m);
           }
         } else {
@@ -792,7 +804,7 @@ EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, cons
               const float alpha = fast_exp2(-delta);
               nm[ft] -= delta;
               NM[ft] = splat(nm[ft]);
-              asm volatile("" : "+a"(NM[ft]));
+              EDTTS_PIN_ACC(NM[ft]);
               lvec[ft] *= alpha;
 #pragma unroll
               for (int dt = 0; dt < DT; ++dt) scale_acc(O[dt][QT * hf + ft], alpha);

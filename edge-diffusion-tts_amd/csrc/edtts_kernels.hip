@@ -865,8 +865,11 @@ EDTTS_DEV void layer_tile(const KArgs& a, float* smem, int wave, int lane, int b
 #ifndef EDTTS_PERSIST
 #define EDTTS_PERSIST 0
 #endif
+#ifndef EDTTS_SMALL_W2
+#define EDTTS_SMALL_W2 0
+#endif
 template <class C, int TAIL, int PART>
-__global__ __launch_bounds__(C::THREADS) void k_layer(KArgs a) {
+__global__ __launch_bounds__(C::THREADS, ((EDTTS_SMALL_W2 && C::NF == 1) || (EDTTS_W2 && C::NF == 2 && C::H == 160)) ? 2 : 1) void k_layer(KArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1590,6 +1593,7 @@ __global__ __launch_bounds__(kDfThreads) void k_dsconv_fused(const float* __rest
 struct Workspace {
   size_t err, h, q, k, vT, kc, vcT, cond, total;  // offsets in floats (err = 0: the index-error word heads every workspace)
   int Tp, Sp, VR;
+  unsigned* errp;  // where kernels record clamped indices: word 0 of the CALLER's workspace, also for a sub-batch's slice of it
 };
 // frame tiles per wave of the default-decoder instance.  Measured (B=256, T=512): NF=4 lifts the FFN phase from 80 % to 88 %
 // MFMA-busy as the bare-stream probe predicts, but the attention phases lose more under the doubled register footprint
@@ -1630,7 +1634,114 @@ static void make_workspace(const Layout& lo, int B, int T, int S, int cond_rows,
   w->vcT = take((size_t)lo.L * B * w->VR * w->Sp / es);
   w->cond = take((size_t)cond_rows * lo.L * 2 * 2 * H + (size_t)cond_rows * H);  // AdaLN rows + t_cond scratch
   w->total = o;
+  w->errp = nullptr;
 }
+
+// SIMDs of the current device = waves of the layer kernels in flight at a time (one per SIMD: they need > 256 registers)
+static int device_simds() {
+  static int n[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 1024;
+  if (!n[dev]) {
+    int cus = 0;
+    n[dev] = (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) ? 4 * cus : 1024;
+  }
+  return n[dev];
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Sub-batches on two streams.  A layer launch of a large batch is a whole number of rounds of one wave per SIMD, and every
+// launch ends with SIMDs idling while the last waves finish (round 3, B=256, T=512: 3.7 % of the kernel, the spread of the
+// sum of four wave lifetimes over 1024 SIMDs); the next launch cannot start before, because it reads K / V rows of its
+// neighbours.  Utterances are independent, though: the samplers cut a large batch into two halves that walk the same
+// launch sequence on two streams (the caller's and a library-owned one, forked and joined with events: capturable), so one
+// half's waves fill the SIMDs the other half's finishing launch leaves idle.  Each half is an ordinary call on its own slice
+// of the caller's workspace; results do not depend on the cut (every utterance is computed alone, bitwise).
+// ---------------------------------------------------------------------------------------------------------
+constexpr int kMaxSub = 4;
+struct SubBatches {
+  int n;                 // 1 (no cut) or 2
+  int B[kMaxSub], off[kMaxSub];
+  Workspace ws[kMaxSub];
+  size_t base[kMaxSub];  // float offset of slice j in the caller's workspace
+  size_t cond;           // float offset of the conditioning rows (shared by the slices)
+  size_t total;          // floats
+};
+static int g_substreams = [] { const char* e = getenv("EDTTS_SUBSTREAMS"); const int v = e ? atoi(e) : 2; return v < 1 ? 1 : (v > kMaxSub ? kMaxSub : v); }();
+
+static void plan_sub(const Layout& lo, int B, int T, int S, int cond_rows, int n, SubBatches* sb) {
+  sb->n = n;
+  if (n == 1) {
+    make_workspace(lo, B, T, S, cond_rows, &sb->ws[0]);
+    sb->B[0] = B; sb->off[0] = 0; sb->base[0] = 0; sb->cond = sb->ws[0].cond; sb->total = sb->ws[0].total;
+    return;
+  }
+  size_t o = 0;
+  int off = 0;
+  for (int j = 0; j < n; ++j) {
+    sb->B[j] = B / n + (j < B % n ? 1 : 0);
+    sb->off[j] = off;
+    off += sb->B[j];
+    make_workspace(lo, sb->B[j], T, S, 1, &sb->ws[j]);
+    sb->base[j] = o;
+    o += sb->ws[j].total;
+  }
+  sb->cond = o;
+  sb->total = align64(o + (size_t)cond_rows * lo.L * 2 * 2 * lo.H + (size_t)cond_rows * lo.H);
+}
+// the cut a sampler call makes: two halves when each still fills every SIMD at least once
+static void plan_call(const Layout& lo, int B, int T, int S, int cond_rows, float* wsb, SubBatches* sb) {
+  Workspace w;
+  make_workspace(lo, 1, T, S, 1, &w);
+  const long waves = (long)B * (w.Tp / 32);
+  // (n halves as long as each still fills every SIMD at least once)
+  int n = g_substreams;
+  while (n > 1 && (B < n || waves < (long)n * device_simds())) --n;
+  plan_sub(lo, B, T, S, cond_rows, n, sb);
+  for (int j = 0; j < sb->n; ++j) sb->ws[j].errp = reinterpret_cast<unsigned*>(wsb);
+}
+
+struct SideStream {
+  hipStream_t s[kMaxSub - 1] = {};
+  hipEvent_t fork = nullptr, join[kMaxSub - 1] = {};
+};
+static thread_local SideStream g_side[64];
+// RAII: fork the side stream off the caller's stream, join it back when the call returns (also on its error paths, so that a
+// stream capture is never left with a dangling branch)
+struct ForkJoin {
+  hipStream_t st[kMaxSub];
+  SideStream* side = nullptr;
+  int n = 1;
+  int init(const SubBatches& sb, hipStream_t main) {
+    for (int j = 0; j < kMaxSub; ++j) st[j] = main;
+    if (sb.n < 2) return EDTTS_OK;
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) return fail(EDTTS_ERR_UNSUPPORTED, "device ordinal %d out of range", dev);
+    SideStream& sd = g_side[dev];
+    if (!sd.fork) HIP_TRY(hipEventCreateWithFlags(&sd.fork, hipEventDisableTiming));
+    for (int j = 0; j + 1 < sb.n; ++j)
+      if (!sd.s[j]) {
+        HIP_TRY(hipStreamCreateWithFlags(&sd.s[j], hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&sd.join[j], hipEventDisableTiming));
+      }
+    HIP_TRY(hipEventRecord(sd.fork, main));
+    for (int j = 0; j + 1 < sb.n; ++j) {
+      HIP_TRY(hipStreamWaitEvent(sd.s[j], sd.fork, 0));
+      st[j + 1] = sd.s[j];
+    }
+    side = &sd;
+    n = sb.n;
+    return EDTTS_OK;
+  }
+  ~ForkJoin() {
+    if (side)
+      for (int j = 0; j + 1 < n; ++j) {
+        (void)hipEventRecord(side->join[j], side->s[j]);
+        (void)hipStreamWaitEvent(st[0], side->join[j], 0);
+      }
+  }
+};
 
 // Philox stream ids (the `step` word of the counter) are split into disjoint domains so that no two draws of one seed can meet
 // (include/edtts.h, "Philox stream ids"): [0, 0x10000) belongs to edtts_randn callers, the samplers' per-step draws live above it.
@@ -1660,7 +1771,8 @@ struct Launcher {
   // after round 3's register savings: 232) would otherwise be packed two waves per SIMD onto HALF of the CUs by the dispatcher
   // (measured: B=32, T=512 at 0.232 ms per layer launch instead of 0.155).  Every launch therefore claims a quarter of the CU's
   // 160 KiB of LDS per wave, whether it uses it or not.
-  static size_t occupancy_lds() { return (size_t)C::WAVES * 40 * 1024; }
+  static bool force_small() { static const bool on = [] { const char* e = getenv("EDTTS_FORCE_SMALL"); return e && e[0] == '1'; }(); return on; }
+  static size_t occupancy_lds() { return ((EDTTS_SMALL_W2 && C::NF == 1 && force_small()) || (EDTTS_W2 && C::NF == 2 && C::H == 160)) ? 0 : (size_t)C::WAVES * 40 * 1024; }
   static size_t ring_lds() { return occupancy_lds(); }
   template <class CC> static size_t stash_lds() { return (size_t)CC::WAVES * CC::HT * CC::NF * 1024; }  // residual parking place
   static size_t layer_lds() {
@@ -1700,7 +1812,7 @@ struct Launcher {
       a.kvd[l] = (unsigned)lo.layer[l].kvd; a.kvn[l] = (unsigned)lo.layer[l].kvn; a.kvu[l] = (unsigned)lo.layer[l].kvu;
     }
     a.kc = wsb + ws.kc; a.vcT = wsb + ws.vcT;
-    a.err = reinterpret_cast<unsigned*>(wsb + ws.err);
+    a.err = ws.errp ? ws.errp : reinterpret_cast<unsigned*>(wsb + ws.err);
     hipLaunchKernelGGL(k_ctx<C2>, dim3(ctx_grid(B, ws.Sp)), dim3(64 * kCtxWaves), 0, st, a);
     LAUNCH_CHECK("k_ctx");
     return EDTTS_OK;
@@ -1736,7 +1848,7 @@ struct Launcher {
     // Small grids: with 32 frames per wave fewer waves than SIMDs would be launched (B = 32 at T = 512: 512 waves for 1024 SIMDs;
     // B = 1: 8) -- the 16-frames-per-wave instance doubles the number of waves.  Same arithmetic per frame, bitwise.
     if constexpr (HAS_SMALL) {
-      if (2 * B * (ws.Tp / C::WF) <= wave_slots())  // ... as long as the doubled wave count still runs in one round
+      if (2 * B * (ws.Tp / C::WF) <= wave_slots() || (EDTTS_SMALL_W2 && Launcher<Small>::force_small()))  // ... as long as the doubled wave count still runs in one round
         return Launcher<Small>::forward(lo, blob, ws, wsb, B, T, S, window, x, cond_row, cond_bstride, tail, eps, x_prev, x0, coef, st,
                                         ddpm, lms, vp);
     }
@@ -1940,7 +2052,7 @@ struct Launcher16 {
       a.kvd[l] = (unsigned)lo.layer[l].kvd; a.kvn[l] = (unsigned)lo.layer[l].kvn; a.kvu[l] = (unsigned)lo.layer[l].kvu;
     }
     a.kc = wsb + ws.kc; a.vcT = wsb + ws.vcT;
-    a.err = reinterpret_cast<unsigned*>(wsb + ws.err);
+    a.err = ws.errp ? ws.errp : reinterpret_cast<unsigned*>(wsb + ws.err);
 #ifndef EDTTS16_CTX_F32
 #define EDTTS16_CTX_F32 0   // 1: the context cache from the fp32-arithmetic kernel (k_ctx<.., bf16 out>), as before
 #endif
@@ -2124,9 +2236,15 @@ int edtts_workspace_bytes(const EdttsDims* dims, int B, int T, int S, int cond_r
   int rc = make_layout(dims, &lo);
   if (rc) return rc;
   if (!out_bytes || B < 1 || T < 1 || S < 1 || cond_rows < 1) return fail(EDTTS_ERR_ARG, "bad workspace query (B=%d T=%d S=%d rows=%d)", B, T, S, cond_rows);
-  Workspace w;
-  make_workspace(lo, B, T, S, cond_rows, &w);
-  *out_bytes = w.total * sizeof(float);
+  // room for either form of a sampler call: the batch in one piece, or cut into sub-batches (plan_call)
+  SubBatches one, two;
+  plan_sub(lo, B, T, S, cond_rows, 1, &one);
+  size_t total = one.total;
+  for (int n = 2; n <= kMaxSub && n <= B; ++n) {
+    plan_sub(lo, B, T, S, cond_rows, n, &two);
+    if (two.total > total) total = two.total;
+  }
+  *out_bytes = total * sizeof(float);
   return EDTTS_OK;
 }
 
@@ -2287,18 +2405,24 @@ int edtts_generate(const EdttsDims* dims, const void* packed, void* workspace, i
   hipStream_t st = (hipStream_t)stream;
   const float* blob = (const float*)packed;
   float* wsb = (float*)workspace;
-  Workspace ws;
-  make_workspace(lo, B, T, S, num_steps, &ws);
-  TRY(launch_cond(lo, blob, nullptr, nullptr, timesteps_host, num_steps, wsb + ws.cond, wsb, st));
+  SubBatches sb;
+  plan_call(lo, B, T, S, num_steps, wsb, &sb);
+  TRY(launch_cond(lo, blob, nullptr, nullptr, timesteps_host, num_steps, wsb + sb.cond, wsb, st));
   const size_t row = (size_t)lo.L * 2 * 2 * lo.H;
+  const size_t per_utt = (size_t)T * lo.MEL;
+  ForkJoin fj;
+  TRY(fj.init(sb, st));
   EDTTS_DISPATCH(lo, {
     TRY(LN::set_attrs());
-    TRY(LN::ctx(lo, blob, ws, wsb, B, S, sem_idx, nullptr, st));
-    for (int i = 0; i < num_steps; ++i) {
-      const float* xin = (i == 0) ? x_T : x_work;
-      TRY(LN::forward(lo, blob, ws, wsb, B, T, S, dims->window, xin, wsb + ws.cond + i * row, 0, TAIL_DDIM, nullptr,
-                               x_work, x0_out, coef_host + 4 * i, st));
-    }
+    for (int j = 0; j < sb.n; ++j)
+      TRY(LN::ctx(lo, blob, sb.ws[j], wsb + sb.base[j], sb.B[j], S, sem_idx + (size_t)sb.off[j] * S, nullptr, fj.st[j]));
+    for (int i = 0; i < num_steps; ++i)
+      for (int j = 0; j < sb.n; ++j) {
+        const size_t o = (size_t)sb.off[j] * per_utt;
+        const float* xin = ((i == 0) ? x_T : x_work) + o;
+        TRY(LN::forward(lo, blob, sb.ws[j], wsb + sb.base[j], sb.B[j], T, S, dims->window, xin, wsb + sb.cond + i * row, 0, TAIL_DDIM,
+                        nullptr, x_work + o, x0_out + o, coef_host + 4 * i, fj.st[j]));
+      }
   });
   return EDTTS_OK;
 }
@@ -2316,27 +2440,37 @@ int edtts_sample_multistep(const EdttsDims* dims, const void* packed, void* work
   hipStream_t st = (hipStream_t)stream;
   const float* blob = (const float*)packed;
   float* wsb = (float*)workspace;
-  Workspace ws;
-  make_workspace(lo, B, T, S, num_steps, &ws);
-  TRY(launch_cond(lo, blob, nullptr, nullptr, timesteps_host, num_steps, wsb + ws.cond, wsb, st));
+  SubBatches sb;
+  plan_call(lo, B, T, S, num_steps, wsb, &sb);
+  TRY(launch_cond(lo, blob, nullptr, nullptr, timesteps_host, num_steps, wsb + sb.cond, wsb, st));
   const size_t row = (size_t)lo.L * 2 * 2 * lo.H;
   const size_t per = (size_t)B * T * lo.MEL;
+  const size_t per_utt = (size_t)T * lo.MEL;
+  for (int i = 0; i < num_steps; ++i) {
+    const int mode = (int)coef_host[8 * i];
+    if (mode < 1 || mode > 3 || mode > i + 1) return fail(EDTTS_ERR_ARG, "step %d: bad solver mode %d", i, mode);
+  }
+  ForkJoin fj;
+  TRY(fj.init(sb, st));
   EDTTS_DISPATCH(lo, {
     TRY(LN::set_attrs());
-    TRY(LN::ctx(lo, blob, ws, wsb, B, S, sem_features ? nullptr : sem_idx, sem_features, st));
-    for (int i = 0; i < num_steps; ++i) {
-      const float* c = coef_host + 8 * i;
-      typename LN::LmsStep ls;
-      ls.k.mode = (int)c[0]; ls.k.p0 = c[1]; ls.k.p1 = c[2]; ls.k.c0 = c[3]; ls.k.c1 = c[4]; ls.k.rinv = c[5]; ls.k.cB = c[6]; ls.k.cC = c[7];
-      if (ls.k.mode < 1 || ls.k.mode > 3 || ls.k.mode > i + 1) return fail(EDTTS_ERR_ARG, "step %d: bad solver mode %d", i, ls.k.mode);
-      // history ring of two slots: step i writes slot i%2; newest previous = slot (i-1)%2, the one before = slot i%2
-      ls.x0_hist = hist + (size_t)(i & 1) * per;
-      ls.h_new = hist + (size_t)((i + 1) & 1) * per;
-      ls.h_old = hist + (size_t)(i & 1) * per;
-      ls.x0_all = x0_all ? x0_all + (size_t)i * per : nullptr;
-      TRY(LN::forward(lo, blob, ws, wsb, B, T, S, dims->window, i == 0 ? x_T : x_out, wsb + ws.cond + i * row, 0, TAIL_LMS,
-                               nullptr, x_out, nullptr, nullptr, st, nullptr, &ls));
-    }
+    for (int j = 0; j < sb.n; ++j)
+      TRY(LN::ctx(lo, blob, sb.ws[j], wsb + sb.base[j], sb.B[j], S, (sem_features || !sem_idx) ? nullptr : sem_idx + (size_t)sb.off[j] * S,
+                  sem_features ? sem_features + (size_t)sb.off[j] * S * lo.SD : nullptr, fj.st[j]));
+    for (int i = 0; i < num_steps; ++i)
+      for (int j = 0; j < sb.n; ++j) {
+        const size_t o = (size_t)sb.off[j] * per_utt;
+        const float* c = coef_host + 8 * i;
+        typename LN::LmsStep ls;
+        ls.k.mode = (int)c[0]; ls.k.p0 = c[1]; ls.k.p1 = c[2]; ls.k.c0 = c[3]; ls.k.c1 = c[4]; ls.k.rinv = c[5]; ls.k.cB = c[6]; ls.k.cC = c[7];
+        // history ring of two slots: step i writes slot i%2; newest previous = slot (i-1)%2, the one before = slot i%2
+        ls.x0_hist = hist + (size_t)(i & 1) * per + o;
+        ls.h_new = hist + (size_t)((i + 1) & 1) * per + o;
+        ls.h_old = hist + (size_t)(i & 1) * per + o;
+        ls.x0_all = x0_all ? x0_all + (size_t)i * per + o : nullptr;
+        TRY(LN::forward(lo, blob, sb.ws[j], wsb + sb.base[j], sb.B[j], T, S, dims->window, (i == 0 ? x_T : x_out) + o,
+                        wsb + sb.cond + i * row, 0, TAIL_LMS, nullptr, x_out + o, nullptr, nullptr, fj.st[j], nullptr, &ls));
+      }
   });
   return EDTTS_OK;
 }
@@ -2354,20 +2488,26 @@ int edtts_sample_ddpm(const EdttsDims* dims, const void* packed, void* workspace
   hipStream_t st = (hipStream_t)stream;
   const float* blob = (const float*)packed;
   float* wsb = (float*)workspace;
-  Workspace ws;
-  make_workspace(lo, B, T, S, num_steps, &ws);
-  TRY(launch_cond(lo, blob, t_all, nullptr, nullptr, num_steps, wsb + ws.cond, wsb, st));  // step_idx = None (train.py:155 usage)
+  SubBatches sb;
+  plan_call(lo, B, T, S, num_steps, wsb, &sb);
+  TRY(launch_cond(lo, blob, t_all, nullptr, nullptr, num_steps, wsb + sb.cond, wsb, st));  // step_idx = None (train.py:155 usage)
   const size_t row = (size_t)lo.L * 2 * 2 * lo.H;
   const size_t per_step = (size_t)B * T * lo.MEL;
+  const size_t per_utt = (size_t)T * lo.MEL;
+  ForkJoin fj;
+  TRY(fj.init(sb, st));
   EDTTS_DISPATCH(lo, {
     TRY(LN::set_attrs());
-    TRY(LN::ctx(lo, blob, ws, wsb, B, S, sem_idx, nullptr, st));
-    for (int i = 0; i < num_steps; ++i) {
-      typename LN::DdpmStep ds{noise_all ? noise_all + (size_t)i * per_step : nullptr, (unsigned long long)seed,
-                                        (unsigned long long)batch_offset * T * lo.MEL, kStreamDdpmStep + (unsigned)i};
-      TRY(LN::forward(lo, blob, ws, wsb, B, T, S, dims->window, i == 0 ? x_T : x_out, wsb + ws.cond + i * row, 0, TAIL_DDPM,
-                               nullptr, x_out, nullptr, coef_host + 3 * i, st, &ds));
-    }
+    for (int j = 0; j < sb.n; ++j)
+      TRY(LN::ctx(lo, blob, sb.ws[j], wsb + sb.base[j], sb.B[j], S, sem_idx + (size_t)sb.off[j] * S, nullptr, fj.st[j]));
+    for (int i = 0; i < num_steps; ++i)
+      for (int j = 0; j < sb.n; ++j) {
+        const size_t o = (size_t)sb.off[j] * per_utt;
+        typename LN::DdpmStep ds{noise_all ? noise_all + (size_t)i * per_step + o : nullptr, (unsigned long long)seed,
+                                 ((unsigned long long)batch_offset + (unsigned long long)sb.off[j]) * T * lo.MEL, kStreamDdpmStep + (unsigned)i};
+        TRY(LN::forward(lo, blob, sb.ws[j], wsb + sb.base[j], sb.B[j], T, S, dims->window, (i == 0 ? x_T : x_out) + o,
+                        wsb + sb.cond + i * row, 0, TAIL_DDPM, nullptr, x_out + o, nullptr, coef_host + 3 * i, fj.st[j], &ds));
+      }
   });
   return EDTTS_OK;
 }
@@ -2614,6 +2754,12 @@ int edtts_debug_set_stamps(void* device_buffer) {
   return EDTTS_OK;
 }
 #endif
+
+int edtts_set_substreams(int n) {
+  const int prev = g_substreams;
+  if (n >= 1 && n <= kMaxSub) g_substreams = n;
+  return prev;
+}
 
 int edtts_profile_enable(int max_records) {
   for (hipEvent_t e : g_prof.start) (void)hipEventDestroy(e);

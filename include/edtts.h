@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define EDTTS_VERSION 300 /* 0.3.0: edtts_dsconv_forward takes a stride; Philox stream-id domains */
+#define EDTTS_VERSION 400 /* 0.4.0: sub-batches on two streams (edtts_set_substreams); the workspace grew accordingly */
 
 enum {
   EDTTS_OK = 0,
@@ -52,7 +52,7 @@ typedef struct EdttsDims {
   int32_t layers;        /* CFG.layers                            */
   int32_t heads;         /* CFG.heads                             */
   int32_t n_mels;        /* CFG.n_mels                            */
-  int32_t ffn_mult;      /* CFG.ffn_mult (only 2 is compiled)     */
+  int32_t ffn_mult;      /* CFG.ffn_mult: 1 .. 4 (a run-time tile count of the FFN phases) */
   int32_t codebook_size; /* CFG.codebook_size: rows of token_emb  */
   int32_t semantic_dim;  /* CFG.semantic_dim: sem_proj input      */
   int32_t window;        /* CFG.attn_window_size; < 0 = full self-attention (window_size=None) */
@@ -254,6 +254,16 @@ int edtts_griffin_lim(const float* spec, int B, int T, int n_fft, int hop, const
  * the launch count per kind (arrays of 2), and resets the counter.  Not graph-capturable while on. */
 int edtts_profile_enable(int max_records);
 int edtts_profile_collect(double* ms_by_kind, int* launches_by_kind);
+
+/* ---- sub-batches on two streams ---------------------------------------------------------------------------
+ * The sampler loops (edtts_generate, edtts_sample_multistep, edtts_sample_ddpm) cut a batch whose layer launches are at least two
+ * full rounds of one wave per SIMD (B * ceil(T/32) >= 2 * 4 * #CUs: B >= 128 at T = 512 on an MI355X) into two halves that walk
+ * the same launch sequence on two streams -- `stream` and a library-owned non-blocking one, forked from and joined back into
+ * `stream` with events inside the call (graph-capturable; the caller sees ordinary stream semantics) -- so that one half's waves
+ * fill the SIMDs the other half's finishing launch leaves idle.  Results do not depend on the cut (bitwise).  n = 1 switches
+ * the cut off (per-kernel profiling wants launches that do not share the device), n = 2 (the default; environment
+ * EDTTS_SUBSTREAMS at load time) switches it on.  Returns the previous value; values outside [1, 2] only query. */
+int edtts_set_substreams(int n);
 
 #ifdef __cplusplus
 }

@@ -1249,3 +1249,48 @@ def test_small_batch_instance_equals_the_large_one():
         e_big = decw(xs, tt, ss, None)
         e_small = decw(xs[:2].contiguous(), tt[:2].contiguous(), ss[:2].contiguous(), None)
         assert torch.equal(e_small, e_big[:2]), (window, T)
+
+
+def test_substreams_do_not_change_results():
+    """A batch of at least two rounds of waves is cut into two halves that run on two streams (include/edtts.h:
+    edtts_set_substreams).  Every utterance is computed alone, so the cut must be invisible: bitwise equal results with the cut
+    off and on, eagerly and from a captured hipGraph (the fork / join events are part of the capture), for an odd batch (halves
+    of different size), for the DDPM sampler's Philox noise (keyed by the GLOBAL utterance index), and an out-of-range token in
+    the SECOND half is still recorded in word 0 of the caller's workspace."""
+    from edge_diffusion_tts_amd import native
+    cfg = CFG(device=DEV)
+    dec = make_decoder(cfg, 0)
+    infer = EdgeInference(cfg, DiffusionSchedule(cfg.diff_steps).to(DEV), torch.nn.Identity(), dec)
+    gen = torch.Generator().manual_seed(12)
+    B, S = 129, 256   # 129 * 16 = 2064 waves >= 2 * 1024 SIMDs: the cut applies; halves of 65 and 64 utterances
+    sem = torch.randint(0, 512, (B, S), generator=gen).to(DEV)
+    x = torch.randn(B, 2 * S, 80, generator=gen).to(DEV)
+    prev = native.set_substreams(1)
+    try:
+        one = infer.generate_mel(sem, 4, x_T=x)
+        one_d = infer.sample_ddpm(sem, 3, x_T=x, seed=11)
+        native.set_substreams(2)
+        two = infer.generate_mel(sem, 4, x_T=x)
+        two_d = infer.sample_ddpm(sem, 3, x_T=x, seed=11)
+        assert torch.equal(one, two) and torch.equal(one_d, two_d)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            out_g = infer.generate_mel(sem, 4, x_T=x)
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out_g, one)
+        # the caller's stream sees ordinary stream semantics: work enqueued right behind the call reads finished results
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s):
+            two_s = infer.generate_mel(sem, 4, x_T=x)
+            chk = two_s.clone()
+        s.synchronize()
+        assert torch.equal(chk, one)
+        bad = sem.clone()
+        bad[B - 1, 5] = 512
+        infer.generate_mel(bad, 4, x_T=x)
+        ws = dec.workspace(B, 2 * S, S, 4, x.device)
+        assert native.index_errors(ws) == 1 and native.index_errors(ws) == 0
+    finally:
+        native.set_substreams(prev)

@@ -98,7 +98,7 @@ def test_library_exports_every_declared_symbol():
     for sym in declared:
         assert hasattr(L, sym), sym
     lib = native.lib()
-    assert lib.edtts_version() == 300
+    assert lib.edtts_version() == 400
 
 
 def test_slot_names_cover_the_state_dict():
