@@ -17,18 +17,24 @@
 #include <stdint.h>
 #include <type_traits>
 
-// Ablation / diagnostic switches change results or add instrumentation ("wrong by construction"): they exist for scratch/ only and
-// need -DEDTTS_EXPERIMENTS next to them, so that a product build can never carry one by accident.
-#if !defined(EDTTS_EXPERIMENTS) && (defined(EDTTS_ABLATE_QKVSTORES) || defined(EDTTS_ABLATE_KVLOADS) || defined(EDTTS_DIAG) || \
-                                    (defined(EDTTS_KV2) && EDTTS_KV2) || (defined(EDTTS_PERSIST) && EDTTS_PERSIST) || \
-                                    (defined(EDTTS_H_DMA) && EDTTS_H_DMA) || (defined(EDTTS_SPLITLOAD) && !EDTTS_SPLITLOAD) || \
-                                    defined(EDTTS_STAMPS) || defined(EDTTS16_ABLATE_BARRIER) || defined(EDTTS16_ABLATE_DMA) || \
-                                    (defined(EDTTS16_SPLIT_BUILD) && EDTTS16_SPLIT_BUILD) || (defined(EDTTS16_PHASES) && EDTTS16_PHASES != 15) || (defined(EDTTS_DS_ABL) && EDTTS_DS_ABL))
-#error "ablation / diagnostic / measured-and-rejected variant switches are scratch-only: add -DEDTTS_EXPERIMENTS"
+// Every EDTTS_* / EDTTS16_* macro that is not part of the public header is a tuning, ablation or diagnostic switch of scratch/:
+// some change results ("wrong by construction"), some select measured-and-rejected variants, some only move a default.  None may
+// reach a product build by accident: setting ANY of them from the command line needs -DEDTTS_EXPERIMENTS next to it.  (This test
+// sits above every `#ifndef X / #define X default`, so `defined(X)` here means "set from outside".)
+#if !defined(EDTTS_EXPERIMENTS) && (                                                                                               \
+    defined(EDTTS_ABLATE_QKVSTORES) || defined(EDTTS_ABLATE_KVLOADS) || defined(EDTTS_DIAG) || defined(EDTTS_KV2) ||                \
+    defined(EDTTS_PERSIST) || defined(EDTTS_H_DMA) || defined(EDTTS_SPLITLOAD) || defined(EDTTS_STAMPS) || defined(EDTTS_DS_ABL) || \
+    defined(EDTTS_FAST_BUILD) || defined(EDTTS_W2) || defined(EDTTS_WAVELOG) || defined(EDTTS_RB) || defined(EDTTS_WMAX) ||        \
+    defined(EDTTS_NF_DEFAULT) || defined(EDTTS_NF_FFN) || defined(EDTTS_STAMP_THREAD) || defined(EDTTS_STAMP_HEAD) ||               \
+    defined(EDTTS16_ABLATE_BARRIER) || defined(EDTTS16_ABLATE_DMA) || defined(EDTTS16_SPLIT_BUILD) || defined(EDTTS16_PHASES) ||    \
+    defined(EDTTS16_NF) || defined(EDTTS16_CTX_F32) || defined(EDTTS16_WIDE_KD_SELF) || defined(EDTTS16_WIDE_KD) ||                 \
+    defined(EDTTS16_W1) || defined(EDTTS16_QLDS) || defined(EDTTS16_KVDEPTH) || defined(EDTTS16_IMG) || defined(EDTTS16_HP) ||      \
+    defined(EDTTS16_FRAG_GROUP) || defined(EDTTS16_EVEN_STEPS) || defined(EDTTS16_ATT_OCC) || defined(EDTTS16_WIDE_BUILD))
+#error "tuning / ablation / diagnostic / measured-and-rejected variant switches are scratch-only: add -DEDTTS_EXPERIMENTS"
 #endif
 
 #ifndef EDTTS_W2
-#define EDTTS_W2 0  // experiment: the 32-frame instances at two waves per SIMD (<= 256 registers, no AGPR-class pins)
+#define EDTTS_W2 0  // measured and rejected (round 4): the default decoder's 32-frame instance at TWO waves per SIMD (<= 256 registers: attention outputs wait in LDS for one projection over all heads, residual through global memory, no AGPR-class pins)
 #endif
 #if EDTTS_W2
 #define EDTTS_PIN_ACC(x) asm volatile("" : "+v"(x))
@@ -90,6 +96,10 @@ struct Cfg {
   // NF = 2), else through this wave's (already consumed) self-attention q rows in global memory
   static constexpr bool Q_IN_LDS = !(EDTTS_W2 && NF == 2) && WF * H * 4 * 2 <= 40 * 1024;  // per wave: a quarter of the CU's 160 KiB (four waves per CU, in 1, 2 or 4 blocks)
   static constexpr int THREADS = 64 * WAVES;
+  // DEFER: the per-head attention outputs O^T wait in LDS (B-operand layout) and ONE projection over all heads follows the last
+  // head, so the 16*NF*HT-register branch tile is not live during the attention steps (see attention_fused)
+  static constexpr bool DEFER = EDTTS_W2 && NF == 2 && H == 160;
+  static constexpr int OHEAD_BYTES = DFULL * NF * 1024 + (DREM ? NF * 512 : 0);  // LDS bytes of one head's O^T tiles (remainder rows as f2)
   static_assert(NF == 1 || NF == 2 || NF == 4, "frame tiles per wave");
   static_assert(H % 32 == 0 && MEL % 16 == 0 && H % HEADS == 0, "dims");
   static_assert(DREM == 0 || DREM == 8, "head_dim % 16 must be 0 or 8");
@@ -379,7 +389,8 @@ EDTTS_DEV float silu(float g) { return g * __builtin_amdgcn_rcpf(1.0f + __expf(-
 // ring the QKV-tail instance spilled (76 B/lane of scratch); 8 fragments = 64 MFMAs of prefetch distance.
 template <class C> constexpr int wstream_ring() {
   constexpr int full = ((C::HT * 2) / C::NF >= 2 && C::HT % ((C::HT * 2) / C::NF) == 0) ? (C::HT * 2) / C::NF : C::HT;
-  return ((C::HT >= 16 || (EDTTS_W2 && C::NF == 2)) && full % 2 == 0) ? full / 2 : full;
+  if (EDTTS_W2 && C::NF == 2 && C::H == 160) return 5;  // (half the prefetch distance in the wave's own MFMAs, the same in time at two waves per SIMD)
+  return (C::HT >= 16 && full % 2 == 0) ? full / 2 : full;
 }
 template <class C> using WStream = FragRing<wstream_ring<C>()>;
 
@@ -435,9 +446,10 @@ struct VFrag {  // V^T fragments (MFMA A operand of P V) of one chunk of key til
 //   !SELF: keys are the S context tokens, no mask (layers/mla.py:158-179)
 // qload.q4(row16, col) / q2(row16, col) return q[m0 + 16*row16 + fq][col + 4 g ...] / [col + 2 g ...] for this lane (col wave-uniform).
 // ---------------------------------------------------------------------------------------------------------
-template <class C, bool SELF, class QLoad>
+template <class C, bool SELF, class QLoad, class BeforeProject>
 EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, const float* __restrict__ VTb, int ldv,
                                int nkeys, int window, int m0w, int lane, WStream<C>& ring, f4 (&h)[C::HT][C::NF],
+                               char* obuf, BeforeProject&& before_project,
                                unsigned long long* stamps = nullptr, int stamp_sel = 0) {
   int sidx = 0;  // (EDTTS_STAMPS diagnostic builds: four stamps per step of the selected head)
   (void)sidx; (void)stamps; (void)stamp_sel;
@@ -871,14 +883,48 @@ EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, cons
     if (hd == STAMP_SEL_HEAD(stamp_sel)) STAMPX(stamps, sidx++, stamp_sel);  // (normalisation done: start of the projection phases)
 #endif
     if (hd + 1 < C::HEADS) prefetch(geo[0], hd + 1, 0);
+    if constexpr (C::DEFER) {
+      // this head's O^T tiles wait in LDS as they stand (C/D layout = the projection's B operand: lane-contiguous, conflict-free)
+      char* ob = obuf + hd * C::OHEAD_BYTES;
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt) {
-      if (DREM && dt == DT - 1) ktile_phase<C::HT, WStream<C>::RN_, NF, 2>(ring, O[dt], h);  // remainder tile: valid k in steps 0, 1 only
-      else ktile_phase<C::HT>(ring, O[dt], h);
+      for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int ft = 0; ft < NF; ++ft) {
+          if (DREM && dt == DT - 1) reinterpret_cast<f2*>(ob + DFULL * NF * 1024 + ft * 512)[lane] = f2{O[dt][ft][0], O[dt][ft][1]};
+          else reinterpret_cast<f4*>(ob + (dt * NF + ft) * 1024)[lane] = O[dt][ft];
+        }
+    } else {
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        if (DREM && dt == DT - 1) ktile_phase<C::HT, WStream<C>::RN_, NF, 2>(ring, O[dt], h);  // remainder tile: valid k in steps 0, 1 only
+        else ktile_phase<C::HT>(ring, O[dt], h);
+      }
     }
 #ifdef EDTTS_STAMPS
     if (hd == STAMP_SEL_HEAD(stamp_sel)) STAMPX(stamps, sidx++, stamp_sel);  // end of the head
 #endif
+  }
+  if constexpr (C::DEFER) {
+    // one projection over all heads, in the order the per-head phases have (same accumulation order: bitwise the same result)
+    before_project();
+    for (int hd = 0; hd < C::HEADS; ++hd) {
+      const char* ob = obuf + hd * C::OHEAD_BYTES;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        f4 in[NF];
+#pragma unroll
+        for (int ft = 0; ft < NF; ++ft) {
+          if (DREM && dt == DT - 1) {
+            const f2 t = reinterpret_cast<const f2*>(ob + DFULL * NF * 1024 + ft * 512)[lane];
+            in[ft] = f4{t[0], t[1], 0.f, 0.f};
+          } else {
+            in[ft] = reinterpret_cast<const f4*>(ob + (dt * NF + ft) * 1024)[lane];
+          }
+        }
+        if (DREM && dt == DT - 1) ktile_phase<C::HT, WStream<C>::RN_, NF, 2>(ring, in, h);
+        else ktile_phase<C::HT>(ring, in, h);
+      }
+    }
   }
 }
 

@@ -668,6 +668,8 @@ EDTTS_DEV void layer_tile(const KArgs& a, float* smem, int wave, int lane, int b
   // this wave's parking place for the residual tile, in REGISTER layout (element [nt][ft] of lane l at ((nt*NF + ft)*64 + l) * 16 B:
   // conflict-free b128 accesses, no padding)
   f4* const stash = reinterpret_cast<f4*>(smem) + (size_t)wave * C::HT * NF * 64 + lane;
+  char* const obuf = reinterpret_cast<char*>(smem) + (size_t)wave * C::HT * NF * 1024;  // (C::DEFER: the heads' O^T tiles share the parking place)
+  static_assert(!C::DEFER || C::HEADS * C::OHEAD_BYTES <= C::HT * NF * 1024, "attention outputs must fit the wave's parking place");
   constexpr int QLDS = C::H;  // q rows unpadded: stash + q tiles fill the CU's 160 KiB exactly at H = 160 (q is read a few times per head)
   float* qtile = smem + (size_t)C::WAVES * C::HT * NF * 256 + (size_t)wave * C::WF * QLDS;  // (only touched when C::Q_IN_LDS)
   const size_t rowbase = (size_t)b * a.Tp + m0 + fq;
@@ -715,25 +717,37 @@ EDTTS_DEV void layer_tile(const KArgs& a, float* smem, int wave, int lane, int b
     dma_tile_to_lds<C::HT, NF>(hp, C::H, reinterpret_cast<f4*>(smem) + (size_t)wave * C::HT * NF * 64);
 #else
     // the residual goes from the h buffer straight to its parking place (the loads fly together with the first head's q / K / V^T)
+    if constexpr (!C::DEFER) {
 #pragma unroll
-    for (int nt = 0; nt < C::HT; ++nt)
+      for (int nt = 0; nt < C::HT; ++nt)
 #pragma unroll
-      for (int ft = 0; ft < NF; ++ft) h[nt][ft] = ldg4(hp + 16 * nt + (size_t)ft * 16 * C::H);
-    park_h();
+        for (int ft = 0; ft < NF; ++ft) h[nt][ft] = ldg4(hp + 16 * nt + (size_t)ft * 16 * C::H);
+      park_h();
+    }
 #endif
     // branch tile starts at the projection bias (attention.py:123); the residual itself stays parked until the branch is done
+    auto init_proj_bias = [&]() {
 #pragma unroll
-    for (int nt = 0; nt < C::HT; ++nt) {
-      const f4 pb = ldg4(a.proj_b + 16 * nt + 4 * g);
+      for (int nt = 0; nt < C::HT; ++nt) {
+        const f4 pb = ldg4(a.proj_b + 16 * nt + 4 * g);
 #pragma unroll
-      for (int ft = 0; ft < NF; ++ft) h[nt][ft] = pb;
-    }
+        for (int ft = 0; ft < NF; ++ft) h[nt][ft] = pb;
+      }
+    };
+    if constexpr (!C::DEFER) init_proj_bias();
     if (DIAG_ON(1)) {
       QGlobal ql(a.q + ((size_t)b * a.Tp + m0) * C::H, C::H, fq, g);
       attention_fused<C, true>(ql, a.k + (size_t)b * a.Tp * C::H, a.vT + (size_t)b * C::VR * a.Tp, a.Tp, a.T, a.window, m0,
-                               lane, ring, h, a.stamps ? a.stamps + 8 : nullptr, a.diag_skip);
+                               lane, ring, h, obuf, init_proj_bias, a.stamps ? a.stamps + 8 : nullptr, a.diag_skip);
     }
-    add_parked_h();
+    if constexpr (C::DEFER) {  // the residual never left the h buffer
+#pragma unroll
+      for (int nt = 0; nt < C::HT; ++nt)
+#pragma unroll
+        for (int ft = 0; ft < NF; ++ft) h[nt][ft] += ldg4(hp + 16 * nt + (size_t)ft * 16 * C::H);
+    } else {
+      add_parked_h();
+    }
     STAMPX(a.stamps, 1, a.diag_skip);
   } else {
 #pragma unroll
@@ -746,7 +760,14 @@ EDTTS_DEV void layer_tile(const KArgs& a, float* smem, int wave, int lane, int b
     {
       f4 hn[C::HT][NF];
       rms_norm_tile<C::HT, NF>(h, a.n2w, nullptr, g, hn);
-      park_h();
+      if constexpr (C::DEFER) {  // LDS holds the attention outputs: the residual waits in this wave's own rows of the h buffer
+#pragma unroll
+        for (int nt = 0; nt < C::HT; ++nt)
+#pragma unroll
+          for (int ft = 0; ft < NF; ++ft) stg4(hp + 16 * nt + (size_t)ft * 16 * C::H, h[nt][ft]);
+      } else {
+        park_h();
+      }
       for (int nt = 0; nt < C::HT; nt += 2) {
         f4 acc[2][NF];
 #pragma unroll
@@ -764,20 +785,30 @@ EDTTS_DEV void layer_tile(const KArgs& a, float* smem, int wave, int lane, int b
       }
     }
     STAMPX(a.stamps, 2, a.diag_skip);
+    auto zero_h = [&]() {
 #pragma unroll
-    for (int nt = 0; nt < C::HT; ++nt)
+      for (int nt = 0; nt < C::HT; ++nt)
 #pragma unroll
-      for (int ft = 0; ft < NF; ++ft) h[nt][ft] = splat(0.f);
+        for (int ft = 0; ft < NF; ++ft) h[nt][ft] = splat(0.f);
+    };
+    if constexpr (!C::DEFER) zero_h();
     if constexpr (C::Q_IN_LDS) {
       QLds ql(qtile, QLDS, fq, g);
       attention_fused<C, false>(ql, a.kc + (size_t)b * a.Sp * C::H, a.vcT + (size_t)b * C::VR * a.Sp, a.Sp, a.S, -1, m0, lane,
-                                ring, h, a.stamps ? a.stamps + 40 : nullptr, a.diag_skip);
+                                ring, h, obuf, zero_h, a.stamps ? a.stamps + 40 : nullptr, a.diag_skip);
     } else {
       QGlobal ql(a.q + ((size_t)b * a.Tp + m0) * C::H, C::H, fq, g);
       attention_fused<C, false>(ql, a.kc + (size_t)b * a.Sp * C::H, a.vcT + (size_t)b * C::VR * a.Sp, a.Sp, a.S, -1, m0, lane,
-                                ring, h);
+                                ring, h, obuf, zero_h);
     }
-    add_parked_h();
+    if constexpr (C::DEFER) {
+#pragma unroll
+      for (int nt = 0; nt < C::HT; ++nt)
+#pragma unroll
+        for (int ft = 0; ft < NF; ++ft) h[nt][ft] += ldg4(hp + 16 * nt + (size_t)ft * 16 * C::H);
+    } else {
+      add_parked_h();
+    }
     STAMPX(a.stamps, 3, a.diag_skip);
   }
   if (PART == PART_ATTN) {  // hand the residual tile to the FFN half
@@ -865,11 +896,8 @@ EDTTS_DEV void layer_tile(const KArgs& a, float* smem, int wave, int lane, int b
 #ifndef EDTTS_PERSIST
 #define EDTTS_PERSIST 0
 #endif
-#ifndef EDTTS_SMALL_W2
-#define EDTTS_SMALL_W2 0
-#endif
 template <class C, int TAIL, int PART>
-__global__ __launch_bounds__(C::THREADS, ((EDTTS_SMALL_W2 && C::NF == 1) || (EDTTS_W2 && C::NF == 2 && C::H == 160)) ? 2 : 1) void k_layer(KArgs a) {
+__global__ __launch_bounds__(C::THREADS, C::DEFER ? 2 : 1) void k_layer(KArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -882,7 +910,19 @@ __global__ __launch_bounds__(C::THREADS, ((EDTTS_SMALL_W2 && C::NF == 1) || (EDT
 #else
   const TileId tl = wave_tile(a.B, a.Tp, C::WAVES, C::WF);
   if (!tl.valid) return;
+#ifdef EDTTS_WAVELOG  // diagnostic builds: when and where every wave of the launch ran (scratch/wavelog.py)
+  const unsigned long long wl_r0 = __builtin_amdgcn_s_memrealtime(), wl_c0 = __builtin_amdgcn_s_memtime();
+#endif
   layer_tile<C, TAIL, PART>(a, smem, wave, lane, tl.b, tl.m0);
+#ifdef EDTTS_WAVELOG
+  if (a.stamps && lane == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    unsigned long long* p = a.stamps + 6 * ((size_t)a.diag_skip + (size_t)tl.b * (a.Tp / C::WF) + tl.m0 / C::WF);
+    p[0] = wl_r0; p[1] = wl_c0; p[2] = __builtin_amdgcn_s_memrealtime(); p[3] = __builtin_amdgcn_s_memtime();
+    p[4] = __builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_ID: wave, simd, pipe, cu, sh, se
+    p[5] = __builtin_amdgcn_s_getreg((31 << 11) | 20);  // XCC_ID
+  }
+#endif
 #endif
 }
 
@@ -1765,14 +1805,17 @@ struct LmsStepArgs {
 #ifdef EDTTS_STAMPS
 static unsigned long long* g_stamps_fwd = nullptr;  // diagnostic builds only, see edtts_debug_set_stamps
 #endif
+#ifdef EDTTS_WAVELOG
+static unsigned long long* g_wavelog = nullptr;  // diagnostic builds only: [layer launches of ONE forward][8192 waves][6]
+static thread_local int g_wavelog_base = 0;       // first wave index of the sub-batch being launched
+#endif
 template <class C>
 struct Launcher {
   // One wave of these kernels per SIMD, on EVERY CU: an instance that needs fewer than 257 registers (the 16-frames-per-wave ones
   // after round 3's register savings: 232) would otherwise be packed two waves per SIMD onto HALF of the CUs by the dispatcher
   // (measured: B=32, T=512 at 0.232 ms per layer launch instead of 0.155).  Every launch therefore claims a quarter of the CU's
   // 160 KiB of LDS per wave, whether it uses it or not.
-  static bool force_small() { static const bool on = [] { const char* e = getenv("EDTTS_FORCE_SMALL"); return e && e[0] == '1'; }(); return on; }
-  static size_t occupancy_lds() { return ((EDTTS_SMALL_W2 && C::NF == 1 && force_small()) || (EDTTS_W2 && C::NF == 2 && C::H == 160)) ? 0 : (size_t)C::WAVES * 40 * 1024; }
+  static size_t occupancy_lds() { return C::DEFER ? 0 : (size_t)C::WAVES * 40 * 1024; }  // (the two-waves-per-SIMD experiment wants eight waves per CU)
   static size_t ring_lds() { return occupancy_lds(); }
   template <class CC> static size_t stash_lds() { return (size_t)CC::WAVES * CC::HT * CC::NF * 1024; }  // residual parking place
   static size_t layer_lds() {
@@ -1848,7 +1891,7 @@ struct Launcher {
     // Small grids: with 32 frames per wave fewer waves than SIMDs would be launched (B = 32 at T = 512: 512 waves for 1024 SIMDs;
     // B = 1: 8) -- the 16-frames-per-wave instance doubles the number of waves.  Same arithmetic per frame, bitwise.
     if constexpr (HAS_SMALL) {
-      if (2 * B * (ws.Tp / C::WF) <= wave_slots() || (EDTTS_SMALL_W2 && Launcher<Small>::force_small()))  // ... as long as the doubled wave count still runs in one round
+      if (2 * B * (ws.Tp / C::WF) <= wave_slots())  // ... as long as the doubled wave count still runs in one round
         return Launcher<Small>::forward(lo, blob, ws, wsb, B, T, S, window, x, cond_row, cond_bstride, tail, eps, x_prev, x0, coef, st,
                                         ddpm, lms, vp);
     }
@@ -1898,6 +1941,10 @@ struct Launcher {
         a.x_prev = x_prev; a.x0 = x0;
         a.c_s1m = coef[0]; a.c_sab = coef[1]; a.c_sabp = coef[2]; a.c_dir = coef[3];
       }
+#ifdef EDTTS_WAVELOG
+      a.stamps = g_wavelog ? g_wavelog + (size_t)6 * 8192 * l : nullptr;
+      a.diag_skip = g_wavelog_base;
+#endif
 #ifdef EDTTS_STAMPS
       a.stamps = g_stamps_fwd ? g_stamps_fwd + 128 * l : nullptr;
 #endif
@@ -1983,9 +2030,13 @@ struct Launcher16 {
   using Small = edtts16::Cfg16<C::H, C::HEADS, C::MEL, 1>;
   // The 64-frames-per-wave instance (every weight fragment read from the LDS ring feeds four MFMAs instead of two, every K / V^T
   // tile four instead of two): measured at config 3 it runs the FFN and tail phases ~28 % faster and the attention ~8 % slower
-  // (one head per step, twice the context working set per XCD) -- 34.25 vs 34.16 ms per call, DESIGN.md 4.5 -- so it is not
-  // selected by default; EDTTS16_WIDE=1 (read once per process) selects it wherever the padded length allows.
-  static constexpr bool HAS_WIDE = C::NF == 2 && C::H == 256;
+  // (one head per step, twice the context working set per XCD) -- 33.50 vs 33.52 ms per call, DESIGN.md 4.5.  Round 4: it did not
+  // earn its place (the bar was >= 3 % at config 3), so it is NOT part of the product library any more: an experiment build
+  // (-DEDTTS_EXPERIMENTS -DEDTTS16_WIDE_BUILD=1) carries it, and EDTTS16_WIDE=1 in the environment then selects it.
+#ifndef EDTTS16_WIDE_BUILD
+#define EDTTS16_WIDE_BUILD 0  // measured and rejected (same speed, 7 more kernels): -DEDTTS_EXPERIMENTS -DEDTTS16_WIDE_BUILD=1 builds it
+#endif
+  static constexpr bool HAS_WIDE = EDTTS16_WIDE_BUILD && C::NF == 2 && C::H == 256;
   using Wide = edtts16::Cfg16<C::H, C::HEADS, C::MEL, 4>;
   static bool use_wide(int B, int Tp) {
     static const bool on = [] { const char* e = getenv("EDTTS16_WIDE"); return e && e[0] == '1'; }();
@@ -2170,6 +2221,13 @@ struct Launcher16 {
 };
 
 // compiled decoder shapes: (hidden, heads, n_mels)
+#ifdef EDTTS_FAST_BUILD  // scratch builds (-DEDTTS_EXPERIMENTS): the default decoder's fp32 instance only
+#define EDTTS_DISPATCH(lo, ...)                                                                          \
+  do {                                                                                                   \
+    if (!(lo).BF16 && (lo).H == 160 && (lo).HEADS == 4 && (lo).MEL == 80) { using LN = Launcher<Cfg<160, 4, 80, EDTTS_NF_DEFAULT>>; __VA_ARGS__; } \
+    else return fail(EDTTS_ERR_UNSUPPORTED, "EDTTS_FAST_BUILD: only the 160/4/80 fp32 instance is compiled");  \
+  } while (0)
+#else
 #define EDTTS_DISPATCH(lo, ...)                                                                          \
   do {                                                                                                   \
     if ((lo).BF16) {                                                                                     \
@@ -2185,6 +2243,7 @@ struct Launcher16 {
     else return fail(EDTTS_ERR_UNSUPPORTED, "no kernel instance for hidden=%d heads=%d n_mels=%d "        \
                      "(compiled: 160/4/80, 256/8/80, 32/2/80, 64/4/16)", (lo).H, (lo).HEADS, (lo).MEL);   \
   } while (0)
+#endif
 
 static int launch_cond(const Layout& lo, const float* blob, const int64_t* t, const int64_t* step_idx, const int64_t* t_host,
                        int rows, float* cond, float* wsb, hipStream_t st) {
@@ -2419,6 +2478,9 @@ int edtts_generate(const EdttsDims* dims, const void* packed, void* workspace, i
     for (int i = 0; i < num_steps; ++i)
       for (int j = 0; j < sb.n; ++j) {
         const size_t o = (size_t)sb.off[j] * per_utt;
+#ifdef EDTTS_WAVELOG
+        g_wavelog_base = sb.off[j] * (sb.ws[j].Tp / 32);
+#endif
         const float* xin = ((i == 0) ? x_T : x_work) + o;
         TRY(LN::forward(lo, blob, sb.ws[j], wsb + sb.base[j], sb.B[j], T, S, dims->window, xin, wsb + sb.cond + i * row, 0, TAIL_DDIM,
                         nullptr, x_work + o, x0_out + o, coef_host + 4 * i, fj.st[j]));
@@ -2751,6 +2813,13 @@ int edtts_griffin_lim(const float* spec, int B, int T, int n_fft, int hop, const
 // Diagnostic builds only (-DEDTTS_STAMPS; scratch/stamps_bf16.py): where block 0 / wave 0 of the bf16 layer kernel spends its cycles.
 int edtts_debug_set_stamps(void* device_buffer) {
   g_stamps_fwd = (unsigned long long*)device_buffer;
+  return EDTTS_OK;
+}
+#endif
+
+#ifdef EDTTS_WAVELOG
+int edtts_debug_set_wavelog(void* device_buffer) {
+  g_wavelog = (unsigned long long*)device_buffer;
   return EDTTS_OK;
 }
 #endif

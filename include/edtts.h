@@ -16,9 +16,8 @@
  *     (a hipStream_t passed as void*; NULL = the null stream).  All calls are graph-capturable.
  *   - return value: 0 on success, a negative EDTTS_ERR_* otherwise; edtts_last_error() returns a
  *     thread-local message for the last failing call.
- *   - environment switches, read once per process: EDTTS16_WIDE=1 selects the 64-frames-per-wave instance of the
- *     (256, 8, 80) bf16 decoder where the padded length is a multiple of 64 (same speed, results equal to the default
- *     instance's within bf16 rounding, not bitwise); EDTTS_DSCONV_UNFUSED=1 forces the three-kernel conv path.
+ *   - environment switches, read once per process: EDTTS_SUBSTREAMS=1|2 (see edtts_set_substreams, default 2);
+ *     EDTTS_DSCONV_UNFUSED=1 forces the three-kernel conv path.
  */
 #ifndef EDTTS_H_
 #define EDTTS_H_

@@ -998,15 +998,20 @@ def test_bf16_full_size_config3_properties():
 
 
 def test_bf16_wide_instance(golden, tmp_path):
-    """The 64-frames-per-wave bf16 instance (EDTTS16_WIDE=1; the library reads the switch once per process, hence the child): the
+    """SCRATCH test since round 4: the 64-frame instance was measured at the default instance's speed and left the product library
+    (-DEDTTS_EXPERIMENTS -DEDTTS16_WIDE_BUILD=1 builds it); runs only when EDTTS_TEST_WIDE_LIB names such a build.
+    The 64-frames-per-wave bf16 instance (EDTTS16_WIDE=1; the library reads the switch once per process, hence the child): the
     config-3 shape against the reference's fp32 golden output and against the default instance on the same input; a 4-step
     sampler run whose utterances straddle blocks: run twice bitwise equal, probed utterances == the same utterances alone
     (bitwise), and bf16-level agreement with the default instance."""
     import os
     import subprocess
     import sys
+    wide_lib = os.environ.get("EDTTS_TEST_WIDE_LIB")
+    if not wide_lib:
+        pytest.skip("the 64-frame bf16 instance is an experiment build (set EDTTS_TEST_WIDE_LIB to a -DEDTTS16_WIDE_BUILD=1 library)")
     out = str(tmp_path / "wide.npz")
-    env = dict(os.environ, EDTTS16_WIDE="1")
+    env = dict(os.environ, EDTTS16_WIDE="1", EDTTS_LIB=wide_lib)
     child = os.path.join(os.path.dirname(os.path.abspath(__file__)), "helpers", "bf16_wide_child.py")
     r = subprocess.run([sys.executable, child, out], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
