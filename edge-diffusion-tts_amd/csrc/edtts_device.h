@@ -379,6 +379,18 @@ EDTTS_DEV float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 // g * sigmoid(g); v_rcp_f32 (1 ulp) instead of the 9-instruction IEEE divide -- relative error ~1e-7, far inside the parity budget
 EDTTS_DEV float silu(float g) { return g * __builtin_amdgcn_rcpf(1.0f + __expf(-g)); }
 
+// v, gt: value / gate accumulators of one hidden tile (before bias) -> value * silu(gate)   (layers/transformer.py:21-23)
+EDTTS_DEV f4 swiglu_tile(f4 v, f4 gt, f4 vb, f4 gb) {
+  v += vb;  // bias after the GEMM: its load is off the MFMA critical path
+  gt += gb;
+  // written on vectors so that the mul / add halves pack (v_pk_*)
+  const f4 e = {fast_exp2(gt[0] * -1.4426950408889634f), fast_exp2(gt[1] * -1.4426950408889634f),
+                fast_exp2(gt[2] * -1.4426950408889634f), fast_exp2(gt[3] * -1.4426950408889634f)};
+  const f4 d = e + 1.0f;
+  const f4 rc = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1]), __builtin_amdgcn_rcpf(d[2]), __builtin_amdgcn_rcpf(d[3])};
+  return (v * gt) * rc;
+}
+
 // weight stream of the layer / prologue kernels: a per-wave register ring of HT fragments straight from L2; the four waves
 // of a block share each fragment through the CU's L1 (measured 86 % TCP hit rate).
 // (A block-shared LDS ring -- each fragment fetched once per block, ds_read_b128 to the MFMA -- was built and measured:
@@ -446,11 +458,17 @@ struct VFrag {  // V^T fragments (MFMA A operand of P V) of one chunk of key til
 //   !SELF: keys are the S context tokens, no mask (layers/mla.py:158-179)
 // qload.q4(row16, col) / q2(row16, col) return q[m0 + 16*row16 + fq][col + 4 g ...] / [col + 2 g ...] for this lane (col wave-uniform).
 // ---------------------------------------------------------------------------------------------------------
-template <class C, bool SELF, class QLoad, class BeforeProject>
+// OMODE: what happens to a head's normalised output O^T --
+//   O_FUSED  project it at once: h += Wo[:, head] . O  (the product kernels)
+//   O_DEFER  park it in LDS (obuf, B-operand layout) and run ONE projection over all heads behind the last head (EDTTS_W2)
+//   O_LDS    park it in LDS and return: the caller projects (cooperative kernel, edtts_coop.h: heads hd0, hd0 + hstep, ... of a
+//            tile are this wave's, the projection is split over the waves by OUTPUT tiles)
+enum { O_FUSED = 0, O_DEFER = 1, O_LDS = 2 };
+template <class C, bool SELF, int OMODE, class QLoad, class BeforeProject>
 EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, const float* __restrict__ VTb, int ldv,
                                int nkeys, int window, int m0w, int lane, WStream<C>& ring, f4 (&h)[C::HT][C::NF],
                                char* obuf, BeforeProject&& before_project,
-                               unsigned long long* stamps = nullptr, int stamp_sel = 0) {
+                               unsigned long long* stamps = nullptr, int stamp_sel = 0, int hd0 = 0, int hstep = 1) {
   int sidx = 0;  // (EDTTS_STAMPS diagnostic builds: four stamps per step of the selected head)
   (void)sidx; (void)stamps; (void)stamp_sel;
   constexpr int DH = C::DH, DFULL = C::DFULL, DREM = C::DREM, DT = C::DT, H = C::H, CH = kChunk, NF = C::NF;
@@ -686,9 +704,9 @@ EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, cons
 #endif
     __builtin_amdgcn_sched_barrier(0);
   };
-  prefetch(geo[0], 0, 0);
+  if (hd0 < C::HEADS) prefetch(geo[0], hd0, 0);
 
-  for (int hd = 0; hd < C::HEADS; ++hd) {
+  for (int hd = hd0; hd < C::HEADS; hd += hstep) {
     f4 O[DT][NF];
 #pragma unroll
     for (int hf = 0; hf < NHALF; ++hf) {
@@ -882,8 +900,8 @@ EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, cons
 #ifdef EDTTS_STAMPS
     if (hd == STAMP_SEL_HEAD(stamp_sel)) STAMPX(stamps, sidx++, stamp_sel);  // (normalisation done: start of the projection phases)
 #endif
-    if (hd + 1 < C::HEADS) prefetch(geo[0], hd + 1, 0);
-    if constexpr (C::DEFER) {
+    if (hd + hstep < C::HEADS) prefetch(geo[0], hd + hstep, 0);
+    if constexpr (OMODE != O_FUSED) {
       // this head's O^T tiles wait in LDS as they stand (C/D layout = the projection's B operand: lane-contiguous, conflict-free)
       char* ob = obuf + hd * C::OHEAD_BYTES;
 #pragma unroll
@@ -904,7 +922,7 @@ EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, cons
     if (hd == STAMP_SEL_HEAD(stamp_sel)) STAMPX(stamps, sidx++, stamp_sel);  // end of the head
 #endif
   }
-  if constexpr (C::DEFER) {
+  if constexpr (OMODE == O_DEFER) {
     // one projection over all heads, in the order the per-head phases have (same accumulation order: bitwise the same result)
     before_project();
     for (int hd = 0; hd < C::HEADS; ++hd) {

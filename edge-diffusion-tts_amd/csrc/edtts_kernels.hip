@@ -737,7 +737,7 @@ EDTTS_DEV void layer_tile(const KArgs& a, float* smem, int wave, int lane, int b
     if constexpr (!C::DEFER) init_proj_bias();
     if (DIAG_ON(1)) {
       QGlobal ql(a.q + ((size_t)b * a.Tp + m0) * C::H, C::H, fq, g);
-      attention_fused<C, true>(ql, a.k + (size_t)b * a.Tp * C::H, a.vT + (size_t)b * C::VR * a.Tp, a.Tp, a.T, a.window, m0,
+      attention_fused<C, true, C::DEFER ? O_DEFER : O_FUSED>(ql, a.k + (size_t)b * a.Tp * C::H, a.vT + (size_t)b * C::VR * a.Tp, a.Tp, a.T, a.window, m0,
                                lane, ring, h, obuf, init_proj_bias, a.stamps ? a.stamps + 8 : nullptr, a.diag_skip);
     }
     if constexpr (C::DEFER) {  // the residual never left the h buffer
@@ -794,11 +794,11 @@ EDTTS_DEV void layer_tile(const KArgs& a, float* smem, int wave, int lane, int b
     if constexpr (!C::DEFER) zero_h();
     if constexpr (C::Q_IN_LDS) {
       QLds ql(qtile, QLDS, fq, g);
-      attention_fused<C, false>(ql, a.kc + (size_t)b * a.Sp * C::H, a.vcT + (size_t)b * C::VR * a.Sp, a.Sp, a.S, -1, m0, lane,
+      attention_fused<C, false, C::DEFER ? O_DEFER : O_FUSED>(ql, a.kc + (size_t)b * a.Sp * C::H, a.vcT + (size_t)b * C::VR * a.Sp, a.Sp, a.S, -1, m0, lane,
                                 ring, h, obuf, zero_h, a.stamps ? a.stamps + 40 : nullptr, a.diag_skip);
     } else {
       QGlobal ql(a.q + ((size_t)b * a.Tp + m0) * C::H, C::H, fq, g);
-      attention_fused<C, false>(ql, a.kc + (size_t)b * a.Sp * C::H, a.vcT + (size_t)b * C::VR * a.Sp, a.Sp, a.S, -1, m0, lane,
+      attention_fused<C, false, C::DEFER ? O_DEFER : O_FUSED>(ql, a.kc + (size_t)b * a.Sp * C::H, a.vcT + (size_t)b * C::VR * a.Sp, a.Sp, a.S, -1, m0, lane,
                                 ring, h, obuf, zero_h);
     }
     if constexpr (C::DEFER) {
@@ -835,16 +835,7 @@ EDTTS_DEV void layer_tile(const KArgs& a, float* smem, int wave, int lane, int b
       gemm_phase_pair<C::HT>(ring, hn, v, gt);
       __builtin_amdgcn_sched_barrier(0);  // one VALU clump between the two MFMA phases: every MFMA<->VALU switch costs ~8 cycles
 #pragma unroll
-      for (int ft = 0; ft < NF; ++ft) {
-        v[ft] += vb;  // bias after the GEMM: its load is off the MFMA critical path
-        gt[ft] += gb;
-        // SwiGLU: value * silu(gate) (transformer.py:21-23), written on vectors so that the mul / add halves pack (v_pk_*)
-        const f4 e = {fast_exp2(gt[ft][0] * -1.4426950408889634f), fast_exp2(gt[ft][1] * -1.4426950408889634f),
-                      fast_exp2(gt[ft][2] * -1.4426950408889634f), fast_exp2(gt[ft][3] * -1.4426950408889634f)};
-        const f4 d = e + 1.0f;
-        const f4 rc = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1]), __builtin_amdgcn_rcpf(d[2]), __builtin_amdgcn_rcpf(d[3])};
-        act[ft] = (v[ft] * gt[ft]) * rc;
-      }
+      for (int ft = 0; ft < NF; ++ft) act[ft] = swiglu_tile(v[ft], gt[ft], vb, gb);  // (edtts_coop.h shares it: transformer.py:21-23)
       __builtin_amdgcn_sched_barrier(0);
       ktile_phase<C::HT>(ring, act, h);
     }
@@ -926,6 +917,7 @@ __global__ __launch_bounds__(C::THREADS, C::DEFER ? 2 : 1) void k_layer(KArgs a)
 #endif
 }
 
+#include "edtts_coop.h"
 #include "edtts_bf16.h"
 #include "edtts_melpost.h"
 
@@ -1707,6 +1699,7 @@ struct SubBatches {
   size_t cond;           // float offset of the conditioning rows (shared by the slices)
   size_t total;          // floats
 };
+static int g_coop = [] { const char* e = getenv("EDTTS_COOP"); return e ? atoi(e) : -1; }();
 static int g_substreams = [] { const char* e = getenv("EDTTS_SUBSTREAMS"); const int v = e ? atoi(e) : 2; return v < 1 ? 1 : (v > kMaxSub ? kMaxSub : v); }();
 
 static void plan_sub(const Layout& lo, int B, int T, int S, int cond_rows, int n, SubBatches* sb) {
@@ -1881,19 +1874,39 @@ struct Launcher {
 #endif
   }
 
+  // The cooperative layer kernel (edtts_coop.h: W waves per frame tile) serves the grids that leave SIMDs idle; compiled for the
+  // default decoder.  Which instance, by the number t32 of 32-frame tiles against the device's SIMD count (bitwise the same results
+  // in every case):
+  //     8 t32 <= SIMDs   16-frame tiles, four waves each      (B = 1, T = 256: 64 waves instead of 16)
+  //     4 t32 <= SIMDs   32-frame tiles, four waves each
+  //     2 t32 <= SIMDs   32-frame tiles, two waves each       (B = 32, T = 512: 1024 waves that keep k_layer's 8 MFMAs per fragment)
+  //     else             k_layer, one wave per 32-frame tile
+  static constexpr bool HAS_COOP = C::NF == 2 && C::H == 160 && C::HEADS == 4 && !SPLIT;
+  static int coop_choice(int B, int Tp) {  // 0: none; 14: NF 1, W 4; 24: NF 2, W 4; 22: NF 2, W 2
+    if (g_coop >= 0) return g_coop;  // (edtts_set_coop: 0 switches the cooperative kernel off, 14 / 24 / 22 force an instance)
+    const int t32 = B * (Tp / 32), slots = wave_slots();
+    return 8 * t32 <= slots ? 14 : (4 * t32 <= slots ? 24 : (2 * t32 <= slots ? 22 : 0));
+  }
   // one decoder forward given conditioning rows + context cache already in the workspace
   using DdpmStep = DdpmStepArgs;
   using LmsStep = LmsStepArgs;
+  template <int COW = 0>
   static int forward(const Layout& lo, const float* blob, const Workspace& ws, float* wsb, int B, int T, int S, int window,
                      const float* x, const float* cond_row, int cond_bstride, int tail, float* eps, float* x_prev, float* x0,
                      const float* coef, hipStream_t st, const DdpmStep* ddpm = nullptr, const LmsStep* lms = nullptr,
                      const VpredStepArgs* vp = nullptr) {
+    if constexpr (HAS_COOP && COW == 0) {
+      const int co = coop_choice(B, ws.Tp);
+      if (co == 14) return Launcher<Small>::template forward<4>(lo, blob, ws, wsb, B, T, S, window, x, cond_row, cond_bstride, tail, eps, x_prev, x0, coef, st, ddpm, lms, vp);
+      if (co == 24) return forward<4>(lo, blob, ws, wsb, B, T, S, window, x, cond_row, cond_bstride, tail, eps, x_prev, x0, coef, st, ddpm, lms, vp);
+      if (co == 22) return forward<2>(lo, blob, ws, wsb, B, T, S, window, x, cond_row, cond_bstride, tail, eps, x_prev, x0, coef, st, ddpm, lms, vp);
+    }
     // Small grids: with 32 frames per wave fewer waves than SIMDs would be launched (B = 32 at T = 512: 512 waves for 1024 SIMDs;
     // B = 1: 8) -- the 16-frames-per-wave instance doubles the number of waves.  Same arithmetic per frame, bitwise.
-    if constexpr (HAS_SMALL) {
+    if constexpr (HAS_SMALL && COW == 0) {
       if (2 * B * (ws.Tp / C::WF) <= wave_slots())  // ... as long as the doubled wave count still runs in one round
-        return Launcher<Small>::forward(lo, blob, ws, wsb, B, T, S, window, x, cond_row, cond_bstride, tail, eps, x_prev, x0, coef, st,
-                                        ddpm, lms, vp);
+        return Launcher<Small>::template forward<0>(lo, blob, ws, wsb, B, T, S, window, x, cond_row, cond_bstride, tail, eps, x_prev, x0, coef, st,
+                                                    ddpm, lms, vp);
     }
     KArgs a;
     base_args(lo, blob, ws, wsb, B, T, S, window, &a);
@@ -1968,7 +1981,16 @@ struct Launcher {
 #undef EDTTS_LAUNCH_FFN
         g_prof.kind = 0;
       } else {
-#define EDTTS_LAUNCH_ALL(TL) PROF_LAUNCH(st, hipLaunchKernelGGL((k_layer<C, TL, PART_ALL>), dim3(g_layer), dim3(C::THREADS), layer_lds(), st, a))
+#define EDTTS_LAUNCH_ALL(TL)                                                                                                            \
+  do {                                                                                                                                  \
+    if constexpr (COW != 0) {                                                                                                           \
+      using CO = Coop<C, (COW ? COW : 4)>;                                                                                              \
+      const int tiles = B * (ws.Tp / C::WF);                                                                                            \
+      PROF_LAUNCH(st, hipLaunchKernelGGL((k_layer_co<C, TL, (COW ? COW : 4)>), dim3((tiles + CO::TILES - 1) / CO::TILES), dim3(256), CO::LDS_BYTES, st, a)); \
+    } else {                                                                                                                            \
+      PROF_LAUNCH(st, hipLaunchKernelGGL((k_layer<C, TL, PART_ALL>), dim3(g_layer), dim3(C::THREADS), layer_lds(), st, a));             \
+    }                                                                                                                                   \
+  } while (0)
         switch (t_eff) {
           case TAIL_QKV: EDTTS_LAUNCH_ALL(TAIL_QKV); break;
           case TAIL_EPS: EDTTS_LAUNCH_ALL(TAIL_EPS); break;
@@ -1995,6 +2017,15 @@ struct Launcher {
     if constexpr (HAS_SMALL) {
       int rc = Launcher<Small>::set_attrs();
       if (rc) return rc;
+    }
+    if constexpr (HAS_COOP) {
+#define EDTTS_CO_ATTR(CC, WW, TL) HIP_TRY(hipFuncSetAttribute((const void*)k_layer_co<CC, TL, WW>, hipFuncAttributeMaxDynamicSharedMemorySize, Coop<CC, WW>::LDS_BYTES))
+#define EDTTS_CO_ATTRS(CC, WW) EDTTS_CO_ATTR(CC, WW, TAIL_QKV); EDTTS_CO_ATTR(CC, WW, TAIL_EPS); EDTTS_CO_ATTR(CC, WW, TAIL_DDIM); EDTTS_CO_ATTR(CC, WW, TAIL_DDPM); EDTTS_CO_ATTR(CC, WW, TAIL_LMS); EDTTS_CO_ATTR(CC, WW, TAIL_VPRED)
+      EDTTS_CO_ATTRS(Small, 4);
+      EDTTS_CO_ATTRS(C, 4);
+      EDTTS_CO_ATTRS(C, 2);
+#undef EDTTS_CO_ATTRS
+#undef EDTTS_CO_ATTR
     }
     const int lds = (int)layer_lds();
     HIP_TRY(hipFuncSetAttribute((const void*)k_prologue<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ring_lds()));
@@ -2823,6 +2854,12 @@ int edtts_debug_set_wavelog(void* device_buffer) {
   return EDTTS_OK;
 }
 #endif
+
+int edtts_set_coop(int mode) {
+  const int prev = g_coop;
+  if (mode == -1 || mode == 0 || mode == 14 || mode == 24 || mode == 22) g_coop = mode;
+  return prev;
+}
 
 int edtts_set_substreams(int n) {
   const int prev = g_substreams;

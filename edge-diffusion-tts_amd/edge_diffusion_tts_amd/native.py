@@ -20,7 +20,7 @@ EXPORTED_SYMBOLS = (
     "edtts_layer_slot_name", "edtts_packed_bytes", "edtts_pack_weights", "edtts_workspace_bytes", "edtts_decoder_forward",
     "edtts_ddim_step", "edtts_ddpm_step", "edtts_generate", "edtts_sample_ddpm", "edtts_sample_multistep", "edtts_dsconv_forward", "edtts_profile_enable",
     "edtts_profile_collect", "edtts_randn", "edtts_index_errors", "edtts_sample_inpaint",
-    "edtts_mel_to_spec", "edtts_griffin_lim_scratch_floats", "edtts_griffin_lim", "edtts_set_substreams",
+    "edtts_mel_to_spec", "edtts_griffin_lim_scratch_floats", "edtts_griffin_lim", "edtts_set_substreams", "edtts_set_coop",
 )
 
 
@@ -81,10 +81,12 @@ def lib() -> C.CDLL:
     L.edtts_profile_enable.argtypes = [i32]
     L.edtts_set_substreams.argtypes = [i32]
     L.edtts_set_substreams.restype = i32
+    L.edtts_set_coop.argtypes = [i32]
+    L.edtts_set_coop.restype = i32
     L.edtts_profile_collect.argtypes = [C.POINTER(C.c_double), C.POINTER(i32)]  # arrays of 2
     for name in EXPORTED_SYMBOLS:
         fn = getattr(L, name)
-        if fn.restype is C.c_int and name not in ("edtts_version", "edtts_num_global_slots", "edtts_num_layer_slots", "edtts_set_substreams"):
+        if fn.restype is C.c_int and name not in ("edtts_version", "edtts_num_global_slots", "edtts_num_layer_slots", "edtts_set_substreams", "edtts_set_coop"):
             fn.errcheck = _errcheck
     _lib = L
     return L
@@ -289,6 +291,12 @@ def set_substreams(n: int) -> int:
     """1: every sampler call runs its batch in one piece; 2 (default): large batches are cut into two halves on two streams
     (include/edtts.h: edtts_set_substreams).  Returns the previous setting."""
     return int(lib().edtts_set_substreams(int(n)))
+
+
+def set_coop(mode: int) -> int:
+    """-1: the cooperative layer kernel is chosen automatically for small grids (default); 0: never; 14 / 24 / 22: force an
+    instance (include/edtts.h: edtts_set_coop).  Returns the previous mode."""
+    return int(lib().edtts_set_coop(int(mode)))
 
 
 def profile_enable(max_records: int) -> None:

@@ -1299,3 +1299,38 @@ def test_substreams_do_not_change_results():
         assert native.index_errors(ws) == 1 and native.index_errors(ws) == 0
     finally:
         native.set_substreams(prev)
+
+
+@pytest.mark.parametrize("B,S,window", [(1, 128, 64), (3, 37, 64), (2, 256, 64), (1, 48, 37), (5, 16, None)])
+def test_cooperative_instances_equal_the_one_wave_ones(B, S, window):
+    """Small grids run the transformer layers with 2 or 4 waves per frame tile (csrc/edtts_coop.h; chosen from the tile count,
+    include/edtts.h: edtts_set_coop).  The split is by heads and by OUTPUT tiles only, so no sum changes: every forced instance
+    (16-frame tiles x 4 waves, 32-frame tiles x 4 and x 2 waves -- the latter with an odd tile count: a block's surplus tile) must
+    equal the one-wave kernels bitwise, for the eps tail (decoder forward), the fused DDIM tail (generate_mel), the DDPM tail with
+    in-kernel noise and the multistep-solver tail; and the automatic choice must be one of them."""
+    from edge_diffusion_tts_amd import DPMSolverPP, native
+    cfg = CFG(device=DEV, attn_window_size=window)
+    dec = make_decoder(cfg, 3)
+    sch = DiffusionSchedule(cfg.diff_steps).to(DEV)
+    infer = EdgeInference(cfg, sch, torch.nn.Identity(), dec)
+    gen = torch.Generator().manual_seed(100 + B + S)
+    sem = torch.randint(0, 512, (B, S), generator=gen).to(DEV)
+    x = torch.randn(B, 2 * S, 80, generator=gen).to(DEV)
+    t = torch.randint(0, 1000, (B,), generator=gen).to(DEV)
+    si = torch.randint(0, 16, (B,), generator=gen).to(DEV)
+    feats = torch.randn(B, S, cfg.semantic_dim, generator=gen).to(DEV)
+
+    def run():
+        return (dec(x, t, sem, si), infer.generate_mel(sem, 4, x_T=x), infer.sample_ddpm(sem, 3, x_T=x, seed=5),
+                DPMSolverPP(sch, order=3).sample(dec, x, feats, num_steps=4))
+
+    prev = native.set_coop(0)
+    try:
+        ref = run()
+        for mode in (14, 24, 22, -1):
+            native.set_coop(mode)
+            out = run()
+            for name, a, b_ in zip(("forward", "generate_mel", "sample_ddpm", "dpm_solver"), ref, out):
+                assert torch.equal(a, b_), f"cooperative instance {mode}: {name} differs from the one-wave kernels (max {max_abs(a.cpu(), b_.cpu()):.3e})"
+    finally:
+        native.set_coop(prev)
