@@ -1924,7 +1924,11 @@ struct Launcher {
     };
     set_qkv(1, 0);  // the prologue writes set 0
     a.n1w = blob + lo.layer[0].n1w; a.stream = blob + lo.inp; a.layer = 0;  // stream: inp | qkv(0)
-    hipLaunchKernelGGL(k_prologue<C>, dim3(g), dim3(C::THREADS), ring_lds(), st, a);
+    if constexpr (COW != 0) {
+      hipLaunchKernelGGL((k_prologue_co<C, (COW ? COW : 4)>), dim3(B * (ws.Tp / C::WF)), dim3(64 * (COW ? COW : 4)), C::HT * C::NF * 1024, st, a);
+    } else {
+      hipLaunchKernelGGL(k_prologue<C>, dim3(g), dim3(C::THREADS), ring_lds(), st, a);
+    }
     LAUNCH_CHECK("k_prologue");
     for (int l = 0; l < lo.L; ++l) {
       const LayerLayout& y = lo.layer[l];
@@ -1986,7 +1990,7 @@ struct Launcher {
     if constexpr (COW != 0) {                                                                                                           \
       using CO = Coop<C, (COW ? COW : 4)>;                                                                                              \
       const int tiles = B * (ws.Tp / C::WF);                                                                                            \
-      PROF_LAUNCH(st, hipLaunchKernelGGL((k_layer_co<C, TL, (COW ? COW : 4)>), dim3((tiles + CO::TILES - 1) / CO::TILES), dim3(256), CO::LDS_BYTES, st, a)); \
+      PROF_LAUNCH(st, hipLaunchKernelGGL((k_layer_co<C, TL, (COW ? COW : 4)>), dim3((tiles + CO::TILES - 1) / CO::TILES), dim3(CO::THREADS), CO::LDS_BYTES, st, a)); \
     } else {                                                                                                                            \
       PROF_LAUNCH(st, hipLaunchKernelGGL((k_layer<C, TL, PART_ALL>), dim3(g_layer), dim3(C::THREADS), layer_lds(), st, a));             \
     }                                                                                                                                   \

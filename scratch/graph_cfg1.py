@@ -1,0 +1,28 @@
+"""B=1, T=256 generate_mel: eager call against a replayed hipGraph of the same call (what would EdgeInference gain by capturing?)"""
+import os, sys, time
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [os.path.join(REPO, "edge-diffusion-tts_amd"), REPO]
+import torch
+from edge_diffusion_tts_amd import CFG, DiffusionSchedule, EdgeDiffusionDecoder, EdgeInference, synth_state_dict, native
+os.chdir("/tmp")
+cfg = CFG(device="cuda")
+dec = EdgeDiffusionDecoder(cfg); dec.load_state_dict(synth_state_dict(cfg, 0)); dec = dec.cuda().eval()
+infer = EdgeInference(cfg, DiffusionSchedule(cfg.diff_steps).to("cuda"), torch.nn.Identity(), dec)
+for B, S in ((1, 128), (1, 256), (4, 128)):
+    sem = torch.randint(0, 512, (B, S), generator=torch.Generator().manual_seed(0)).cuda()
+    def timeit(fn, n=300):
+        for _ in range(20): fn()
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(n): fn()
+        torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e3
+    eager = timeit(lambda: infer.generate_mel(sem, 4, seed=1))
+    x = native.randn((B, 2 * S, 80), "cuda", 1)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = infer.generate_mel(sem, 4, x_T=x)
+    def replay():
+        x.copy_(native.randn((B, 2 * S, 80), "cuda", 1)); g.replay(); return out.clone()
+    gr = timeit(replay)
+    gr_only = timeit(lambda: g.replay())
+    print(f"B={B} T={2*S}: eager {eager:.4f} ms | noise draw + graph replay + clone {gr:.4f} ms | replay alone {gr_only:.4f} ms")
