@@ -119,8 +119,11 @@ def pmc_traffic(args):
 def spawn_ranks(n):
     """`python bench.py --gpus N` without an outer torchrun: start N copies of this script, one per GPU (RANK / LOCAL_RANK /
     WORLD_SIZE / MASTER_* set as torch.distributed.run would), relay rank 0's JSON line, exit with the worst child status.
-    The parent never imports torch or touches a GPU (a process that has initialised the GPU must not exec or fork workers);
-    a rank that dies takes the others down instead of leaving them waiting in a collective."""
+    The parent only compiles the library when it is stale (hipcc; __graft_entry__.compile_library imports neither torch nor the
+    package and dlopens nothing) -- a process that has initialised the GPU must not fork workers.  A rank that dies takes the
+    others down instead of leaving them waiting in a collective, and so does the parent's own death (interrupt, driver timeout):
+    the exact PIDs started here are terminated, then killed."""
+    import signal
     import socket
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -128,25 +131,45 @@ def spawn_ranks(n):
     base = dict(os.environ, WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), EDTTS_BENCH_SPAWNED="1")
     base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (RCCL across processes needs it on this driver)
     import __graft_entry__
-    __graft_entry__.build()  # once, before any rank starts (hipcc only; no GPU call)
+    __graft_entry__.compile_library()  # once, before any rank starts
     procs = []
-    for r in range(n):
-        env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=None if r == 0 else subprocess.DEVNULL))
+
+    def on_signal(signum, _frame):
+        raise KeyboardInterrupt(f"signal {signum}")
+
+    old = {sig: signal.signal(sig, on_signal) for sig in (signal.SIGTERM, signal.SIGINT)}
     rc = 0
-    live = list(procs)
-    while live:
-        time.sleep(0.2)
-        for p in list(live):
-            code = p.poll()
-            if code is None:
-                continue
-            live.remove(p)
-            if code != 0 and rc == 0:
-                rc = code
-                for q in live:  # exact PIDs we started
-                    q.terminate()
+    try:
+        for r in range(n):
+            env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                          stdout=None if r == 0 else subprocess.DEVNULL))
+        live = list(procs)
+        while live:
+            time.sleep(0.2)
+            for p in list(live):
+                code = p.poll()
+                if code is None:
+                    continue
+                live.remove(p)
+                if code != 0 and rc == 0:
+                    rc = code
+                    for q in live:  # exact PIDs we started
+                        q.terminate()
+    except KeyboardInterrupt:
+        rc = rc or 130
+    finally:
+        for p in procs:  # whatever is still alive when we leave (normal exit: nothing)
+            if p.poll() is None:
+                p.terminate()
+        deadline = time.time() + 10
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.1, deadline - time.time()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+        for sig, h in old.items():
+            signal.signal(sig, h)
     return rc
 
 

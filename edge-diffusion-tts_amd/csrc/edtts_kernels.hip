@@ -989,7 +989,10 @@ __global__ __launch_bounds__(64 * kCtxWaves) void k_ctx(CtxArgs a) {
 #pragma unroll
     for (int nt = 0; nt < C::HT; ++nt) ctx[nt][ft] += ldg4(row + 16 * nt);  // decoder.py:93
   }
-  for (int l = 0; l < a.L; ++l) {
+  // (small grids: gridDim.y blocks share a token tile's layers -- the embedding above is recomputed per block, the layers are not)
+  const int lpb = (a.L + (int)gridDim.y - 1) / (int)gridDim.y;
+  const int l_end = ((int)blockIdx.y + 1) * lpb < a.L ? ((int)blockIdx.y + 1) * lpb : a.L;
+  for (int l = (int)blockIdx.y * lpb; l < l_end; ++l) {
     // c = RMSNorm_R(kv_down(ctx))   (mla.py:144-145)
     f4 c[C::RT][2];
     {
@@ -1139,7 +1142,10 @@ __global__ __launch_bounds__(C::THREADS, 1) void k_ctx16(CtxArgs a) {
 #pragma unroll
     for (int ft = 0; ft < 2; ++ft) xin[kt][ft] = pack8(ctx[2 * kt][ft], ctx[2 * kt + 1][ft]);
   const size_t hstride = (size_t)32 * a.Sp;
-  for (int l = 0; l < a.L; ++l) {
+  // (small grids: gridDim.y blocks share a token tile's layers -- the embedding above is recomputed per block, the layers are not)
+  const int lpb = (a.L + (int)gridDim.y - 1) / (int)gridDim.y;
+  const int l_end = ((int)blockIdx.y + 1) * lpb < a.L ? ((int)blockIdx.y + 1) * lpb : a.L;
+  for (int l = (int)blockIdx.y * lpb; l < l_end; ++l) {
     // c = RMSNorm_R(kv_down(ctx))   (mla.py:144-145)
     f4 c[RT][2];
 #pragma unroll
@@ -1849,7 +1855,11 @@ struct Launcher {
     }
     a.kc = wsb + ws.kc; a.vcT = wsb + ws.vcT;
     a.err = ws.errp ? ws.errp : reinterpret_cast<unsigned*>(wsb + ws.err);
-    hipLaunchKernelGGL(k_ctx<C2>, dim3(ctx_grid(B, ws.Sp)), dim3(64 * kCtxWaves), 0, st, a);
+    // one block per token tile group walks all layers -- unless that leaves most of the chip idle (B = 1: one block): then the
+    // layers of a tile go to separate blocks
+    const int gx = ctx_grid(B, ws.Sp);
+    const int gy = (gx * 4 <= wave_slots() / 4) ? lo.L : 1;
+    hipLaunchKernelGGL(k_ctx<C2>, dim3(gx, gy), dim3(64 * kCtxWaves), 0, st, a);
     LAUNCH_CHECK("k_ctx");
     return EDTTS_OK;
   }
@@ -2720,6 +2730,21 @@ int edtts_ddpm_step(const float* alphas, const float* alpha_bar, const float* be
   return EDTTS_OK;
 }
 
+// the one-kernel path: the reference's shape class, and the raw rows of one 128-frame pass must fit the staging tile
+static bool dsconv_takes_fused_path(int C_in, int C_out, int To, int ksize, int stride) {
+  static const bool no_fused = [] { const char* e = getenv("EDTTS_DSCONV_UNFUSED"); return e && e[0] == '1'; }();
+  return !no_fused && C_in <= 80 && C_out <= 160 && To <= 512 && (kDfT - 1) * stride + ksize <= 260;
+}
+
+int edtts_dsconv_scratch_floats(int B, int C_in, int C_out, int T, int ksize, int stride, int groups, size_t* out_floats) {
+  if (!out_floats) return fail(EDTTS_ERR_ARG, "out_floats is NULL");
+  if (B < 1 || C_in < 1 || C_out < 1 || T < 1 || ksize < 1 || stride < 1 || groups < 1) return fail(EDTTS_ERR_ARG, "bad sizes");
+  const int To = (T + 2 * (ksize / 2) - ksize) / stride + 1;
+  if (To < 1) return fail(EDTTS_ERR_ARG, "no output frames (T=%d, kernel %d, stride %d)", T, ksize, stride);
+  *out_floats = dsconv_takes_fused_path(C_in, C_out, To, ksize, stride) ? 0 : (size_t)B * C_out * To + (size_t)2 * B * groups;
+  return EDTTS_OK;
+}
+
 int edtts_dsconv_forward(const float* x, const float* dw, const float* pw, const float* pb, const float* gn_w, const float* gn_b,
                          int B, int C_in, int C_out, int T, int ksize, int stride, int groups, float* scratch, float* y, void* stream) {
   if (!x || !dw || !pw || !pb || !gn_w || !gn_b || !y) return fail(EDTTS_ERR_ARG, "NULL pointer argument");
@@ -2730,8 +2755,7 @@ int edtts_dsconv_forward(const float* x, const float* dw, const float* pw, const
   hipStream_t st = (hipStream_t)stream;
   // Fused path (z never leaves the registers of one 512-thread block per utterance): the reference's own shape class
   // (C_in <= 80, C_out <= 160, T_out <= 512) -- HBM traffic = x in + y out.
-  static const bool no_fused = [] { const char* e = getenv("EDTTS_DSCONV_UNFUSED"); return e && e[0] == '1'; }();
-  if (!no_fused && C_in <= 80 && C_out <= 160 && To <= 512 && (kDfT - 1) * stride + ksize <= 260) {
+  if (dsconv_takes_fused_path(C_in, C_out, To, ksize, stride)) {
     static bool attr_done[64] = {};
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
@@ -2745,7 +2769,7 @@ int edtts_dsconv_forward(const float* x, const float* dw, const float* pw, const
     LAUNCH_CHECK("k_dsconv_fused");
     return EDTTS_OK;
   }
-  if (!scratch) return fail(EDTTS_ERR_ARG, "this shape takes the three-kernel path: scratch (B*C_out*T_out + 2*B*groups floats) required");
+  if (!scratch) return fail(EDTTS_ERR_ARG, "this shape takes the three-kernel path: scratch required (edtts_dsconv_scratch_floats: B*C_out*T_out + 2*B*groups floats)");
   float* z = scratch;
   float* stats = scratch + (size_t)B * C_out * To;
   const int Cip = (C_in + 15) & ~15;

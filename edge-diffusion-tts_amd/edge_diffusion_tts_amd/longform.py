@@ -120,11 +120,27 @@ class InpaintSampler:
             out.append((int(start_sample / sample_rate * 16000) // 320, int(end_sample / sample_rate * 16000) // 320))
         return out
 
+    @staticmethod
+    def chunk_plan(total_frames: int, chunk_frames: int, overlap_frames: int, hop_length: int, chunk_samples: Optional[int] = None,
+                   overlap_samples: Optional[int] = None, total_samples: Optional[int] = None):
+        """(n_chunks, chunk_samples, hop_samples) of the sliding window, inference_pipeline.py:221-225: the sample counts are used
+        verbatim when given (the reference fixes THEM and derives the frame counts), else rebuilt as frames * hop_length."""
+        chunk_samples = int(chunk_samples) if chunk_samples is not None else chunk_frames * hop_length
+        overlap_samples = int(overlap_samples) if overlap_samples is not None else overlap_frames * hop_length
+        total_samples = int(total_samples) if total_samples is not None else total_frames * hop_length
+        hop_samples = chunk_samples - overlap_samples
+        if hop_samples <= 0:
+            raise ValueError(f"need overlap_samples < chunk_samples, got {overlap_samples} / {chunk_samples}")
+        n_chunks = max(1, -(-(total_samples - overlap_samples) // hop_samples))  # int(np.ceil(...)), :225
+        return n_chunks, chunk_samples, hop_samples
+
     @torch.no_grad()
     def generate_long(self, sem_features: torch.Tensor, total_frames: int, chunk_frames: int, overlap_frames: int,
                       chunk_stats, *, strength: float = 0.999, steps: int = 10, cfg_scale: float = 1.0, seed: int = 0,
                       latent_slices: Optional[List[tuple]] = None, hop_length: Optional[int] = None,
-                      sample_rate: Optional[int] = None, draws: Optional[List[dict]] = None) -> torch.Tensor:
+                      sample_rate: Optional[int] = None, draws: Optional[List[dict]] = None,
+                      chunk_samples: Optional[int] = None, overlap_samples: Optional[int] = None,
+                      total_samples: Optional[int] = None) -> torch.Tensor:
         """The reference's context-aware sliding window (inference_pipeline.py:296-367), statement for statement:
 
             for chunk i (hop = chunk_frames - overlap_frames frames apart):
@@ -146,6 +162,12 @@ class InpaintSampler:
         default computed from ``hop_length`` / ``sample_rate`` (cfg values) exactly as the reference does.  ``draws`` (parity
         tests): per chunk a dict with the reference's torch.randn draws ``x_coarse``, ``noise`` and (chunks with a known tail)
         ``noise_k``; otherwise they come from the library's Philox streams.
+        ``chunk_samples`` / ``overlap_samples`` / ``total_samples``: the reference works the other way round -- it FIXES the sample
+        counts (int(2.0 s * sample_rate), int(0.5 s * sample_rate), wav.shape[1]; :221-225) and derives the frame counts through a
+        centred mel transform (frames = samples // hop + 1: 201 / 51 frames for 32000 / 8000 samples at hop 160), so frames * hop
+        over-states them (8160 instead of 8000 overlap samples) and the chunk count can come out one short.  A caller that mirrors
+        the reference passes its sample counts here and they are used verbatim for the chunk count and the semantic slices; the
+        defaults (frames * hop_length) serve callers that think in frames.
         The chunk loop is sequential by construction (chunk i is conditioned on the tail of chunk i-1)."""
         dev = sem_features.device
         M = self.cfg.n_mels
@@ -154,10 +176,8 @@ class InpaintSampler:
         hop_frames = chunk_frames - overlap_frames
         hop_length = int(hop_length if hop_length is not None else self.cfg.hop_length)
         sample_rate = int(sample_rate if sample_rate is not None else self.cfg.sample_rate)
-        chunk_samples, overlap_samples = chunk_frames * hop_length, overlap_frames * hop_length
-        hop_samples = chunk_samples - overlap_samples
-        total_samples = total_frames * hop_length
-        n_chunks = max(1, -(-(total_samples - overlap_samples) // hop_samples))  # int(np.ceil(...)), :225
+        n_chunks, chunk_samples, hop_samples = self.chunk_plan(total_frames, chunk_frames, overlap_frames, hop_length, chunk_samples,
+                                                                overlap_samples, total_samples)
         if len(chunk_stats) != n_chunks:
             raise ValueError(f"chunk_stats must hold {n_chunks} (mean, std) pairs, got {len(chunk_stats)}")
         if latent_slices is None:

@@ -20,7 +20,7 @@ EXPORTED_SYMBOLS = (
     "edtts_layer_slot_name", "edtts_packed_bytes", "edtts_pack_weights", "edtts_workspace_bytes", "edtts_decoder_forward",
     "edtts_ddim_step", "edtts_ddpm_step", "edtts_generate", "edtts_sample_ddpm", "edtts_sample_multistep", "edtts_dsconv_forward", "edtts_profile_enable",
     "edtts_profile_collect", "edtts_randn", "edtts_index_errors", "edtts_sample_inpaint",
-    "edtts_mel_to_spec", "edtts_griffin_lim_scratch_floats", "edtts_griffin_lim", "edtts_set_substreams", "edtts_set_coop",
+    "edtts_mel_to_spec", "edtts_griffin_lim_scratch_floats", "edtts_griffin_lim", "edtts_set_substreams", "edtts_set_coop", "edtts_dsconv_scratch_floats",
 )
 
 
@@ -78,6 +78,7 @@ def lib() -> C.CDLL:
     L.edtts_sample_multistep.argtypes = [C.POINTER(EdttsDims), vp, vp, i32, i32, i32, vp, vp, vp, i32, C.POINTER(C.c_int64),
                                          C.POINTER(f32), vp, vp, vp, vp]
     L.edtts_dsconv_forward.argtypes = [vp] * 6 + [i32] * 7 + [vp, vp, vp]
+    L.edtts_dsconv_scratch_floats.argtypes = [i32] * 7 + [C.POINTER(sz)]
     L.edtts_profile_enable.argtypes = [i32]
     L.edtts_set_substreams.argtypes = [i32]
     L.edtts_set_substreams.restype = i32
@@ -240,11 +241,14 @@ def dsconv_forward(x, dw, pw, pb, gn_w, gn_b, groups: int, stride: int = 1) -> t
     if To < 1:
         raise EdttsError(f"dsconv: no output frames for T={T}, kernel_size={ks}, stride={stride}")
     y = torch.empty(B, Co, To, device=x.device, dtype=torch.float32)
-    scratch = torch.empty(B * Co * To + 2 * B * groups, device=x.device, dtype=torch.float32)
+    need = C.c_size_t(0)
+    lib().edtts_dsconv_scratch_floats(B, Ci, Co, T, ks, int(stride), groups, C.byref(need))  # 0: the one-kernel path
+    scratch = torch.empty(need.value, device=x.device, dtype=torch.float32) if need.value else None
     f = torch.float32
     lib().edtts_dsconv_forward(_dev_ptr(x, f, "x"), _dev_ptr(dw, f, "depthwise.weight"), _dev_ptr(pw, f, "pointwise.weight"),
                                _dev_ptr(pb, f, "pointwise.bias"), _dev_ptr(gn_w, f, "norm.weight"), _dev_ptr(gn_b, f, "norm.bias"),
-                               B, Ci, Co, T, ks, int(stride), groups, scratch.data_ptr(), y.data_ptr(), _stream(x.device))
+                               B, Ci, Co, T, ks, int(stride), groups, None if scratch is None else scratch.data_ptr(), y.data_ptr(),
+                               _stream(x.device))
     return y
 
 

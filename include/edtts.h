@@ -217,9 +217,12 @@ int edtts_sample_inpaint(const EdttsDims* dims, const void* packed, void* worksp
  * x [B,C_in,T] channel-first; dw [C_in,k] depthwise taps (Conv1d(k, stride, padding = k/2, groups = C_in, no bias),
  * conv.py:33-41: T_out = (T + 2*(k/2) - k) / stride + 1); pw [C_out,C_in], pb [C_out]; GroupNorm(groups, eps 1e-5, affine
  * gn_w/gn_b [C_out]) then exact (erf) GELU -> y [B,C_out,T_out].
- * C_in <= 80, C_out <= 160, T_out <= 512 (the reference's shape class) run as ONE kernel whose intermediate never leaves
- * registers (scratch may be NULL); other shapes take a three-kernel path and need scratch of at least
- * B*C_out*T_out + 2*B*groups floats. */
+ * C_in <= 80, C_out <= 160, T_out <= 512 AND 127 * stride + ksize <= 260 (the reference's shape class: k = 3 / 5 at stride 1 or 2;
+ * the raw rows of one 128-frame pass must fit the kernel's staging tile) run as ONE kernel whose intermediate never leaves
+ * registers, and scratch may be NULL; every other shape (stride 3, a large ksize, more channels or frames) takes a three-kernel
+ * path and needs scratch of B*C_out*T_out + 2*B*groups floats -- a NULL scratch is then EDTTS_ERR_ARG.
+ * edtts_dsconv_scratch_floats answers for a given shape: 0 (one kernel, no scratch) or that count. */
+int edtts_dsconv_scratch_floats(int B, int C_in, int C_out, int T, int ksize, int stride, int groups, size_t* out_floats);
 int edtts_dsconv_forward(const float* x, const float* dw, const float* pw, const float* pb, const float* gn_w,
                          const float* gn_b, int B, int C_in, int C_out, int T, int ksize, int stride, int groups,
                          float* scratch, float* y, void* stream);

@@ -1334,3 +1334,28 @@ def test_cooperative_instances_equal_the_one_wave_ones(B, S, window):
                 assert torch.equal(a, b_), f"cooperative instance {mode}: {name} differs from the one-wave kernels (max {max_abs(a.cpu(), b_.cpu()):.3e})"
     finally:
         native.set_coop(prev)
+
+
+def test_bench_two_ranks_rehearsal():
+    """The multi-rank path of bench.py with the REAL sampler, as the driver starts it (`python bench.py --gpus 2`, no launcher
+    around it): a fresh child process spawns two ranks before anything touches the GPU; with EDTTS_BENCH_REHEARSAL=1 both share
+    this box's one GPU and the all-gather runs over gloo.  Checks the contract of the line, not its numbers (not a scaling
+    measurement): one JSON line, two ranks joined, an all-gather was timed, the weak-scaling aggregate is consistent."""
+    import json
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, EDTTS_BENCH_REHEARSAL="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "EDTTS_BENCH_STUB"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "8",
+                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["steps"] == 2 and d["scaling"] == "weak"
+    assert d["allgather_ms"] > 0 and d["allgather_bytes"] == 2 * 8 * 512 * 80 * 4
+    assert d["config"]["batch_per_gpu"] == 8 and "REHEARSAL" in d["note"]
+    assert abs(d["value"] - 2 * 8 * 512 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]

@@ -285,3 +285,26 @@ def test_workspace_cache_evicts_least_recently_used():
     assert dec.workspace(1, 32, 16, 1, "cpu") is a and dec.workspace(3, 32, 16, 1, "cpu") is c and dec.workspace(4, 32, 16, 1, "cpu") is d
     assert dec.workspace(2, 32, 16, 1, "cpu") is not b and len(dec._workspaces) == 3
     assert a.dtype == torch.uint8 and not bool(a.any())
+
+
+def test_longform_chunk_count_follows_the_reference_sample_arithmetic():
+    """inference_pipeline.py:221-236 fixes the SAMPLE counts (2.0 s / 0.5 s at 16 kHz = 32000 / 8000) and derives the frame counts
+    through a centred mel transform (frames = samples // hop + 1 = 201 / 51 at hop 160).  Rebuilding samples from those frame
+    counts over-states them (51 * 160 = 8160) and loses a chunk whenever (N - 8000) lies less than 160 samples above a multiple of
+    24000; with the sample counts handed over, the chunk count is the reference's for every length."""
+    import math
+    from edge_diffusion_tts_amd.longform import InpaintSampler
+    sr, hop = 16000, 160
+    cs, ov = int(2.0 * sr), int(0.5 * sr)
+    cf, of = cs // hop + 1, ov // hop + 1
+    assert (cf, of) == (201, 51)
+    lost = 0
+    for N in list(range(40000, 40000 + 24000, 37)) + [8000 + 24000 * k + d for k in (1, 2, 5) for d in (-1, 0, 1, 100, 159, 160, 161)]:
+        total_frames = N // hop + 1
+        ref = int(math.ceil((N - ov) / (cs - ov)))
+        n, c, h = InpaintSampler.chunk_plan(total_frames, cf, of, hop, chunk_samples=cs, overlap_samples=ov, total_samples=N)
+        assert (n, c, h) == (max(1, ref), cs, cs - ov), N
+        lost += InpaintSampler.chunk_plan(total_frames, cf, of, hop)[0] != max(1, ref)
+    assert lost > 0  # (the frame-derived default does differ on this geometry: that is what the arguments are for)
+    with pytest.raises(ValueError):
+        InpaintSampler.chunk_plan(100, 50, 10, hop, chunk_samples=8000, overlap_samples=8000)

@@ -119,3 +119,36 @@ def test_bench_spawned_rank_failure_ends_the_job():
     r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--config", "5", "--steps", "1"], env=env,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode != 0
+
+
+def test_bench_parent_interrupted_takes_its_ranks_down():
+    """The launcher parent killed (driver timeout, Ctrl-C) must not leave N ranks running on the GPUs: SIGTERM to the parent ends
+    the exact children it started.  Stub ranks that would run for a long time; the parent is terminated once they are up."""
+    import signal
+    import subprocess
+    import sys
+    import time
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, EDTTS_BENCH_STUB="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.Popen([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "200000", "--warmup", "1", "--batch", "4",
+                          "--frames", "32"], env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+
+    def children():
+        out = subprocess.run(["ps", "-o", "pid=", "--ppid", str(p.pid)], capture_output=True, text=True).stdout.split()
+        return [int(x) for x in out]
+
+    deadline = time.time() + 120
+    kids = []
+    while time.time() < deadline and len(kids) < 2:
+        time.sleep(0.5)
+        kids = children()
+    assert len(kids) == 2, "the two ranks did not start"
+    time.sleep(2.0)
+    p.send_signal(signal.SIGTERM)
+    assert p.wait(timeout=60) != 0
+    time.sleep(0.5)
+    for k in kids:
+        alive = subprocess.run(["ps", "-p", str(k), "-o", "stat="], capture_output=True, text=True).stdout.strip()
+        assert alive == "" or alive.startswith("Z"), f"rank process {k} survived its parent ({alive})"
