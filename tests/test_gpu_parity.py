@@ -942,8 +942,7 @@ def test_bf16_sampler_vs_reference_autocast(golden):
     """The bar for the bf16 sampler comes from the reference itself: its own generate_mel under torch.autocast("cpu", bfloat16)
     against its fp32 run on the same weights, tokens and start noise (tests/golden/make_golden_r3.py: bf16_sampler).  bf16
     rounding of eps is amplified 64171x at t=999 where x0 is not clamped, so the error of ANY bf16 run is a
-    distribution with a heavy tail; ours must be no worse than the reference's own at the median, the 99th percentile and --
-    outside the t=999 band -- the maximum."""
+    distribution with a heavy tail; ours must be no worse than the reference's own (cmp_bf16_error_distributions)."""
     g = golden("bf16_sampler")
     H, L, heads = (int(v) for v in g["cfg"].tolist())
     cfg = CFG(hidden=H, layers=L, heads=heads, device=DEV)
@@ -954,13 +953,39 @@ def test_bf16_sampler_vs_reference_autocast(golden):
     ours = infer.generate_mel(cu(g["sem_idx"]), 4, x_T=cu(g["x_T"])).cpu()
     ref = g["out_f32"].double()
     e_ours, e_ref = (ours.double() - ref).abs(), (g["out_autocast"].double() - ref).abs()
-    band = amplification_band(g["x_T"], g["eps0"], k=64.0)  # a bf16 eps error (~1e-2) moves |x0| by up to ~600 before the clamp
+    cmp_bf16_error_distributions(e_ours, e_ref, "bf16 4-step sampler (hidden 64) vs the reference's fp32 run")
+    assert float(ours.abs().max()) <= 3.0 and bool(torch.isfinite(ours).all())
+
+
+def cmp_bf16_error_distributions(e_ours, e_ref, what):
+    """ours vs the reference's own autocast(bf16) run, both as |x - x_fp32|.  A bf16 rounding of eps (~1e-2) is amplified 64171x at
+    t = 999 where x0 is not clamped, so a few elements of ANY bf16 run flip across the whole clamp range: the
+    maximum is the clamp range (5.9 of 6) for both runs whatever band is cut out -- round 3's "maximum outside a k = 64 band"
+    compared 5.90 with 5.79 and could not fail, so it is gone.  What binds: the median, the 90th and the 99th percentile (each at
+    most 1.1 x the reference's), and the NUMBER of flipped elements (error > 0.5: at most 1.25 x the reference's + 2)."""
     q = lambda e, p: float(e.flatten().quantile(p))
-    print(f"bf16 4-step sampler vs the reference's fp32 run: ours median {q(e_ours, .5):.2e} p99 {q(e_ours, .99):.2e} max outside the band "
-          f"{float(e_ours[~band].max()):.2e} | reference autocast(bf16): median {q(e_ref, .5):.2e} p99 {q(e_ref, .99):.2e} max outside "
-          f"{float(e_ref[~band].max()):.2e} | in band: {int(band.sum())} of {band.numel()}")
-    assert q(e_ours, .5) <= 1.1 * q(e_ref, .5) and q(e_ours, .99) <= 1.1 * q(e_ref, .99)
-    assert float(e_ours[~band].max()) <= 1.1 * float(e_ref[~band].max())
+    big = lambda e: int((e > 0.5).sum())
+    print(f"{what}: ours median {q(e_ours, .5):.2e} p90 {q(e_ours, .9):.2e} p99 {q(e_ours, .99):.2e} flipped {big(e_ours)} | reference "
+          f"autocast(bf16): median {q(e_ref, .5):.2e} p90 {q(e_ref, .9):.2e} p99 {q(e_ref, .99):.2e} flipped {big(e_ref)} of {e_ref.numel()}")
+    for p_ in (.5, .9, .99):
+        assert q(e_ours, p_) <= 1.1 * q(e_ref, p_), (what, p_, q(e_ours, p_), q(e_ref, p_))
+    assert big(e_ours) <= 1.25 * big(e_ref) + 2, (what, big(e_ours), big(e_ref))
+
+
+def test_bf16_sampler_cfg3_shape_vs_reference_autocast(golden):
+    """The same bar at BASELINE config 3's decoder shape (hidden 256, 8 layers, 8 heads; one utterance, T = 512), from the
+    reference's own fp32 and autocast(bf16) runs of the 4-step sampler (tests/golden/make_golden_r4.py)."""
+    g = golden("bf16_sampler_cfg3")
+    H, L, heads = (int(v) for v in g["cfg"].tolist())
+    cfg = CFG(hidden=H, layers=L, heads=heads, device=DEV)
+    dec = EdgeDiffusionDecoder(cfg, compute_dtype="bf16")
+    dec.load_state_dict(synth_state_dict(cfg, 1))
+    dec = dec.to(DEV).eval()
+    infer = EdgeInference(cfg, DiffusionSchedule(cfg.diff_steps).to(DEV), torch.nn.Identity(), dec)
+    ours = infer.generate_mel(cu(g["sem_idx"]), 4, x_T=cu(g["x_T"])).cpu()
+    ref = g["out_f32"].double()
+    cmp_bf16_error_distributions((ours.double() - ref).abs(), (g["out_autocast"].double() - ref).abs(),
+                                 "bf16 4-step sampler, config-3 decoder shape, vs the reference's fp32 run")
     assert float(ours.abs().max()) <= 3.0 and bool(torch.isfinite(ours).all())
 
 
@@ -988,13 +1013,13 @@ def test_bf16_full_size_config3_properties():
     idx = [0, 131, 255]
     small = infer.generate_mel(sem[idx].contiguous(), 4, x_T=x[idx].contiguous())
     assert torch.equal(small, big[idx])
-    # one utterance against the fp32 INSTANCE of the same decoder (the oracle needs minutes at this size): bf16-level agreement
-    d32 = EdgeDiffusionDecoder(cfg, max_len=1024)
-    d32.load_state_dict(synth_state_dict(cfg, 1, max_pos=1024))
-    d32 = d32.to(DEV).eval()
-    t, si = torch.full((1,), 600, device=DEV), torch.full((1,), 1, device=DEV)
-    e16, e32 = dec(x[131:132].contiguous(), t, sem[131:132].contiguous(), si), d32(x[131:132].contiguous(), t, sem[131:132].contiguous(), si)
-    assert rms(e16.cpu(), e32.cpu()) < BF16_RMS_TOL and max_abs(e16.cpu(), e32.cpu()) < BF16_MAX_TOL
+    # one utterance of the big batch, single forward, against the CPU ORACLE (fp32; one utterance of T = 1024 is ~20 GFLOP: seconds)
+    sd = synth_state_dict(cfg, 1, max_pos=1024)
+    t, si = torch.full((1,), 600), torch.full((1,), 1)
+    e16 = dec(x[131:132].contiguous(), cu(t), sem[131:132].contiguous(), cu(si)).cpu()
+    ref = O.decoder_forward(sd, x[131:132].cpu(), t, sem[131:132].cpu(), si, heads=8, window=cfg.attn_window_size)
+    print(f"config 3, utterance 131 of the full batch, forward vs the oracle: rms {rms(e16, ref):.2e} max {max_abs(e16, ref):.2e}")
+    assert rms(e16, ref) < BF16_RMS_TOL and max_abs(e16, ref) < BF16_MAX_TOL
 
 
 def test_bf16_wide_instance(golden, tmp_path):
@@ -1034,8 +1059,11 @@ def test_bf16_wide_instance(golden, tmp_path):
     ref = infer.generate_mel(sem, 4, x_T=x).cpu()
     d = (w["big"] - ref).abs()
     print(f"wide vs default instance, 4-step sampler: rms {rms(w['big'], ref):.2e} median {float(d.median()):.2e} max {float(d.max()):.2e}")
-    # (two bf16 runs differ like either differs from fp32: a heavy tail from the t=999 amplification, SURVEY.md F5 -- the median is the bar)
-    assert bool(torch.isfinite(w["big"]).all()) and float(w["big"].abs().max()) <= 3.0 and float(d.median()) < 2e-2
+    # (two bf16 runs differ like either differs from fp32: a heavy tail from the t=999 amplification, SURVEY.md F5.  The bar for the
+    # median is what the reference's own autocast(bf16) run differs from its fp32 run at this decoder shape, doubled for two bf16 runs)
+    gs = golden("bf16_sampler_cfg3")
+    bar = 2.0 * float((gs["out_autocast"].double() - gs["out_f32"].double()).abs().median())
+    assert bool(torch.isfinite(w["big"]).all()) and float(w["big"].abs().max()) <= 3.0 and float(d.median()) < bar, (float(d.median()), bar)
 
 
 def test_bf16_no_cross_block_hazard_when_utterances_straddle_block_rounds():
