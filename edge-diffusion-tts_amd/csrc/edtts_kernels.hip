@@ -2273,6 +2273,14 @@ struct Launcher16 {
     else return fail(EDTTS_ERR_UNSUPPORTED, "EDTTS_FAST_BUILD: only the 160/4/80 fp32 instance is compiled");  \
   } while (0)
 #else
+// Further fp32 shapes are a BUILD option, not a source edit: EDTTS_INSTANCES="192x6x80,128x4x80" in the environment of
+// __graft_entry__.build() becomes -DEDTTS_EXTRA_INSTANCES(lo,...)=EDTTS_X(lo,192,6,80,__VA_ARGS__)... (hidden % 32 == 0, head_dim % 16
+// in {0, 8}, n_mels % 16 == 0; the build's no-scratch gate rejects a shape whose tiles do not fit the register file).
+#ifndef EDTTS_EXTRA_INSTANCES
+#define EDTTS_EXTRA_INSTANCES(lo, ...)
+#define EDTTS_EXTRA_NAMES ""
+#endif
+#define EDTTS_X(lo, HH, HD, MM, ...) else if ((lo).H == HH && (lo).HEADS == HD && (lo).MEL == MM) { using LN = Launcher<Cfg<HH, HD, MM>>; __VA_ARGS__; }
 #define EDTTS_DISPATCH(lo, ...)                                                                          \
   do {                                                                                                   \
     if ((lo).BF16) {                                                                                     \
@@ -2285,8 +2293,9 @@ struct Launcher16 {
     else if ((lo).H == 256 && (lo).HEADS == 8 && (lo).MEL == 80) { using LN = Launcher<Cfg<256, 8, 80>>; __VA_ARGS__; }     \
     else if ((lo).H == 32 && (lo).HEADS == 2 && (lo).MEL == 80) { using LN = Launcher<Cfg<32, 2, 80>>; __VA_ARGS__; }       \
     else if ((lo).H == 64 && (lo).HEADS == 4 && (lo).MEL == 16) { using LN = Launcher<Cfg<64, 4, 16>>; __VA_ARGS__; }       \
+    EDTTS_EXTRA_INSTANCES(lo, __VA_ARGS__)                                                               \
     else return fail(EDTTS_ERR_UNSUPPORTED, "no kernel instance for hidden=%d heads=%d n_mels=%d "        \
-                     "(compiled: 160/4/80, 256/8/80, 32/2/80, 64/4/16)", (lo).H, (lo).HEADS, (lo).MEL);   \
+                     "(compiled: 160/4/80, 256/8/80, 32/2/80, 64/4/16" EDTTS_EXTRA_NAMES "; more: EDTTS_INSTANCES at build time)", (lo).H, (lo).HEADS, (lo).MEL);   \
   } while (0)
 #endif
 

@@ -1387,3 +1387,36 @@ def test_bench_two_ranks_rehearsal():
     assert d["allgather_ms"] > 0 and d["allgather_bytes"] == 2 * 8 * 512 * 80 * 4
     assert d["config"]["batch_per_gpu"] == 8 and "REHEARSAL" in d["note"]
     assert abs(d["value"] - 2 * 8 * 512 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+
+
+def test_build_time_instance_192_6_80_vs_oracle():
+    """A decoder shape that is not built in (hidden 192, 6 heads of 32, n_mels 80) arrives through the build-time instance list
+    (__graft_entry__.DEFAULT_INSTANCES / EDTTS_INSTANCES): single forward and the 4-step sampler against the CPU oracle, and a shape
+    that is in neither list is refused with the list in the message."""
+    import os
+    import __graft_entry__ as G
+    if "192x6x80" not in os.environ.get("EDTTS_INSTANCES", G.DEFAULT_INSTANCES):
+        pytest.skip("this library was built without the 192x6x80 instance")
+    cfg = CFG(hidden=192, heads=6, layers=3, device=DEV)
+    sd = synth_state_dict(cfg, 4)
+    dec = EdgeDiffusionDecoder(cfg)
+    dec.load_state_dict(sd)
+    dec = dec.to(DEV).eval()
+    gen = torch.Generator().manual_seed(77)
+    B, S = 3, 41   # T = 82: ragged against the 32-frame tiles
+    sem = torch.randint(0, 512, (B, S), generator=gen)
+    x = torch.randn(B, 2 * S, 80, generator=gen)
+    t = torch.tensor([999, 500, 3])
+    si = torch.tensor([0, 7, 15])
+    e = dec(cu(x), cu(t), cu(sem), cu(si)).cpu()
+    ref = O.decoder_forward(sd, x, t, sem, si, heads=6)
+    assert max_abs(e, ref) < FWD_TOL, max_abs(e, ref)
+    infer = EdgeInference(cfg, DiffusionSchedule(cfg.diff_steps).to(DEV), torch.nn.Identity(), dec)
+    out = infer.generate_mel(cu(sem), 4, x_T=cu(x)).cpu()
+    tr = []
+    ref_out = O.generate_mel(sd, O.schedule_tables(1000)["alpha_bar"], sem, x, 4, heads=6, trace=tr)
+    e2e_check(out, ref_out, amplification_band(x, tr[0]["eps"]), "192/6/80 instance, 4-step sampler vs oracle")
+    from edge_diffusion_tts_amd import native
+    bad = EdgeDiffusionDecoder(CFG(hidden=224, heads=7, device=DEV)).to(DEV).eval()
+    with pytest.raises(native.EdttsError, match="192/6/80"):
+        bad(torch.zeros(1, 32, 80, device=DEV), torch.zeros(1, dtype=torch.long, device=DEV), torch.zeros(1, 16, dtype=torch.long, device=DEV))

@@ -308,3 +308,17 @@ def test_longform_chunk_count_follows_the_reference_sample_arithmetic():
     assert lost > 0  # (the frame-derived default does differ on this geometry: that is what the arguments are for)
     with pytest.raises(ValueError):
         InpaintSampler.chunk_plan(100, 50, 10, hop, chunk_samples=8000, overlap_samples=8000)
+
+
+def test_build_time_instance_list():
+    """Further fp32 decoder shapes are a build option (EDTTS_INSTANCES -> -D flags for the dispatch), not a source edit."""
+    import __graft_entry__ as G
+    assert G.instance_flags("") == [] and G.instance_flags("160x4x80") == []  # built-in shapes are not repeated
+    f = G.instance_flags("192x6x80, 128x4x80,192x6x80")
+    assert f[0] == "-DEDTTS_EXTRA_INSTANCES(lo,...)=EDTTS_X(lo,192,6,80,__VA_ARGS__) EDTTS_X(lo,128,4,80,__VA_ARGS__)"
+    assert f[1] == '-DEDTTS_EXTRA_NAMES=", 192/6/80, 128/4/80"'
+    for bad in ("100x4x80", "192x5x80", "192x6x81", "96x4x80x1", "abc"):
+        with pytest.raises(ValueError):
+            G.instance_flags(bad)
+    # the product build carries the default list, and the flags are part of the stale check
+    assert all(x in G.FLAGS for x in G.instance_flags(os.environ.get("EDTTS_INSTANCES", G.DEFAULT_INSTANCES)))
