@@ -196,7 +196,23 @@ class EdgeDiffusionDecoder(nn.Module):
         self._workspaces[key] = ws  # (re-)inserted last = most recently used
         if ws.is_cuda and torch.cuda.is_current_stream_capturing():
             self._pinned_workspaces.add(key)
+            if len(self._pinned_workspaces) > self.WORKSPACE_CACHE:
+                import warnings
+                warnings.warn(f"EdgeDiffusionDecoder: {len(self._pinned_workspaces)} workspaces are pinned by captured graphs (more than "
+                              f"WORKSPACE_CACHE = {self.WORKSPACE_CACHE}); call release_pinned() for shapes whose graphs are gone",
+                              RuntimeWarning, stacklevel=3)
         return ws
+
+    def release_pinned(self, B: Optional[int] = None, T: Optional[int] = None, S: Optional[int] = None) -> int:
+        """Un-pin (and drop) the workspaces that were handed out during graph capture -- all of them, or those of one (B, T, S).
+        A pin is keyed by shape, not by graph, and the decoder cannot see a hipGraph die: call this once the graphs that replay
+        into those workspaces have been destroyed (replaying one afterwards would write into freed memory).  Returns the number
+        of workspaces released."""
+        keys = [k for k in self._pinned_workspaces if (B is None or k[0] == B) and (T is None or k[1] == T) and (S is None or k[2] == S)]
+        for k in keys:
+            self._pinned_workspaces.discard(k)
+            self._workspaces.pop(k, None)
+        return len(keys)
 
     # ------------------------------------------------------------------------------------------ forward
     @torch.no_grad()

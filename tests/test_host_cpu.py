@@ -322,3 +322,25 @@ def test_build_time_instance_list():
             G.instance_flags(bad)
     # the product build carries the default list, and the flags are part of the stale check
     assert all(x in G.FLAGS for x in G.instance_flags(os.environ.get("EDTTS_INSTANCES", G.DEFAULT_INSTANCES)))
+
+
+def test_pinned_workspaces_can_be_released(monkeypatch):
+    """Workspaces handed out during graph capture are pinned (a replay writes into them); release_pinned() drops them once the
+    graphs are gone, and a decoder that accumulates more pins than its cache warns."""
+    import warnings
+    dec = EdgeDiffusionDecoder(CFG(device="cpu"))
+    monkeypatch.setattr(native, "workspace_bytes", lambda *a: 64)
+    fake = {"on": False}
+    monkeypatch.setattr(torch.cuda, "is_current_stream_capturing", lambda: fake["on"])
+
+    class Fake(torch.Tensor):
+        is_cuda = True
+    monkeypatch.setattr(torch, "zeros", lambda *a, **k: torch.Tensor._make_subclass(Fake, torch.empty(4)))
+    fake["on"] = True
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        for i in range(dec.WORKSPACE_CACHE + 1):
+            dec.workspace(1 + i, 32, 16, 4, "cpu")
+    assert len(dec._pinned_workspaces) == dec.WORKSPACE_CACHE + 1 and any("pinned" in str(x.message) for x in w)
+    assert dec.release_pinned(B=1) == 1 and dec.release_pinned() == dec.WORKSPACE_CACHE
+    assert not dec._pinned_workspaces and not dec._workspaces
