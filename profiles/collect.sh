@@ -9,6 +9,9 @@ TAG=${1:-r02}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"
+# every profiled pass times k_layer ALONE on the device: the two-stream cut of large batches (edtts_set_substreams, round 4) would
+# let two launches share the SIMDs and stretch each one's duration; the un-profiled bench at the end runs the default
+export EDTTS_SUBSTREAMS=1
 CMD="python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-pmc"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o t -- $CMD > "$OUT/bench_under_trace.json" 2> "$OUT/trace.err"
 for P in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA" \
@@ -17,5 +20,7 @@ for P in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM
   tag=$(echo $P | cut -d" " -f1)
   rocprofv3 --pmc $P --output-format csv -d "$OUT/pmc_$tag" -o pmc -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-pmc > /dev/null 2> "$OUT/pmc_$tag.err" || echo "PMC pass $tag failed"
 done
+unset EDTTS_SUBSTREAMS
 python3 bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"
+python3 bench.py --substreams 1 --no-pmc --no-cpu-baseline > "$OUT/bench_substreams1.json" 2> "$OUT/bench_substreams1.err"
 python3 profiles/summarise.py "$TAG" "$OUT"

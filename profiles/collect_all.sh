@@ -1,6 +1,6 @@
 #!/bin/bash
 # Everything the round's evidence needs, in one gpurun call (from the repo root):  bash profiles/collect_all.sh r02
-TAG=${1:-r03}
+TAG=${1:-r04}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/all_$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"
@@ -15,11 +15,10 @@ timeout -k 10 200 python3 bench.py --batch 32 --no-pmc --no-cpu-baseline > "$OUT
 timeout -k 10 300 python3 bench.py --config 5 --no-pmc > "$OUT/bench_cfg5.json" 2> "$OUT/bench_cfg5.err"
 timeout -k 10 200 python3 bench.py --config 3 --batch 32 --steps 20 --no-pmc --no-cpu-baseline > "$OUT/bench_cfg3_b32.json" 2> "$OUT/bench_cfg3_b32.err"
 timeout -k 10 200 python3 bench.py --config 3 --batch 16 --steps 30 --no-pmc --no-cpu-baseline > "$OUT/bench_cfg3_b16.json" 2> "$OUT/bench_cfg3_b16.err"
-echo "== config 3, 64-frame bf16 instance (EDTTS16_WIDE=1)"
-export EDTTS16_WIDE=1
-timeout -k 10 300 python3 bench.py --config 3 --no-cpu-baseline > "$OUT/bench_cfg3_bf16_wide.json" 2> "$OUT/bench_cfg3_bf16_wide.err"
-timeout -k 10 600 bash scratch/pmc_cfg3.sh "${TAG}w" > "$OUT/pmc_cfg3_wide.log" 2>&1
-unset EDTTS16_WIDE
+timeout -k 10 200 python3 bench.py --batch 8 --no-pmc --no-cpu-baseline > "$OUT/bench_b8.json" 2> "$OUT/bench_b8.err"
+EDTTS_COOP=0 timeout -k 10 200 python3 bench.py --config 1 --no-pmc --no-cpu-baseline > "$OUT/bench_cfg1_coop0.json" 2> "$OUT/bench_cfg1_coop0.err"
+EDTTS_COOP=0 timeout -k 10 200 python3 bench.py --batch 32 --no-pmc --no-cpu-baseline > "$OUT/bench_b32_coop0.json" 2> "$OUT/bench_b32_coop0.err"
+echo "== kernel timeline of one B=1 call"; timeout -k 10 200 bash scratch/trace_cfg.sh cfg1 --config 1 > "$OUT/trace_cfg1.txt" 2>&1
 echo "== elementwise"; timeout -k 10 200 python3 scratch/bench_elementwise.py 2>/dev/null > "$OUT/elementwise.json"
 echo "== ring probe"; timeout -k 5 60 scratch/ring_probe > "$OUT/ring_probe.txt" 2>&1
 ls -la "$OUT"

@@ -4,6 +4,7 @@ TAG=${1:-cfg3}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/pmc_$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"
+export EDTTS_SUBSTREAMS=1  # per-kernel numbers: launches must not share the device
 CMD="python3 bench.py --config 3 --steps 2 --warmup 1 --no-cpu-baseline --no-pmc --no-roofline"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o t -- $CMD > "$OUT/bench.json" 2> "$OUT/trace.err"
 for P in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA" \
