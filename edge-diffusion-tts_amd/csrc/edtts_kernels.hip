@@ -1437,7 +1437,9 @@ __global__ __launch_bounds__(128) void k_dsconv_norm(const float* __restrict__ z
 // reference's GroupNorm).  Shape limits (else edtts_dsconv_forward takes the three-kernel path): C_in <= 16 KT, C_out <= 16 CT,
 // T_out <= 128 NP.
 // ---------------------------------------------------------------------------------------------------------
-constexpr int kDfT = 128, kDfWaves = kDfT / 16, kDfThreads = 64 * kDfWaves;
+constexpr int kDfT = 128;  // frames per pass of the eight-wave form (any stride whose raw rows fit: 127 * stride + ksize <= 260)
+constexpr int kDfTWide = 256;  // ... of the sixteen-wave form (stride 1, ksize <= 5: 255 + ksize <= 260): four waves per SIMD (128 registers: the z
+                               // tile of a wave is 80 of them) overlap one wave's staging, taps and stores with another's MFMAs -- round 4
 constexpr int kDfXld = 260;  // raw input frames per pass and channel: 127 * stride + ksize <= 260; 4 rows apart = 16 banks apart: the four lane groups of a depthwise read (rows 4 g + r) fall on disjoint banks
 template <int KT, int CT>
 constexpr int dsconv_fused_lds_floats() { return 16 * CT * (16 * KT + 4) + 16 * KT * kDfXld; }
@@ -1457,11 +1459,12 @@ EDTTS_DEV float erf_as(float x) {
 #ifndef EDTTS_DS_ABL
 #define EDTTS_DS_ABL 0   // timing ablations (-DEDTTS_EXPERIMENTS; results wrong): 1 no erf, 2 no stores, 4 no MFMAs, 8 no input staging, 16 no statistics
 #endif
-template <int KT, int CT, int NP>
-__global__ __launch_bounds__(kDfThreads) void k_dsconv_fused(const float* __restrict__ x, const float* __restrict__ dw, const float* __restrict__ pw,
+template <int KT, int CT, int NP, int TP>
+__global__ __launch_bounds__(TP * 4) void k_dsconv_fused(const float* __restrict__ x, const float* __restrict__ dw, const float* __restrict__ pw,
                                                              const float* __restrict__ pb, const float* __restrict__ gw, const float* __restrict__ gb,
                                                              int Ci, int Co, int T, int To, int ks, int stride, int groups, float* __restrict__ y) {
   extern __shared__ __attribute__((aligned(16))) float dsm_all[];
+  constexpr int kDfT = TP, kDfWaves = TP / 16, kDfThreads = 64 * kDfWaves;  // (shadow the eight-wave constants)
   constexpr int Cip = 16 * KT, WLD = Cip + 4;
   float* wsm = dsm_all;                  // [16 CT][WLD] pointwise weights (rows >= Co and columns >= Ci zero)
   float* xs = dsm_all + 16 * CT * WLD;   // [Cip][kDfXld] raw input frames of the current pass (zero outside [0, T)); reused for the statistics
@@ -1551,7 +1554,8 @@ __global__ __launch_bounds__(kDfThreads) void k_dsconv_fused(const float* __rest
   float* wsum = xs;                          // [waves][16 CT]
   float* chs = xs + kDfWaves * 16 * CT;      // [16 CT] per-channel totals
   float* gst = chs + 16 * CT;                // [groups][2]: mean, rstd
-  auto channel_reduce = [&](bool centred) {
+  auto channel_reduce = [&](auto centred_tag) {
+    constexpr bool centred = decltype(centred_tag)::value;  // (compile-time: the plain-sum pass must not carry the centring arithmetic)
     __syncthreads();  // xs / wsum free
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
@@ -1564,8 +1568,12 @@ __global__ __launch_bounds__(kDfThreads) void k_dsconv_fused(const float* __rest
         for (int r = 0; r < 4; ++r) {
           const int to = p * kDfT + 16 * wave + 4 * g + r;
           if (to < To && co < Co) {
-            const float d = acc[ct][p][r] - mu;
-            s += centred ? d * d : d;
+            if (centred) {
+              const float d = acc[ct][p][r] - mu;
+              s += d * d;
+            } else {
+              s += acc[ct][p][r];
+            }
           }
         }
       s += __shfl_xor(s, 16, 64);  // over the four lane groups (frames 4 g + r of the wave's 16)
@@ -1593,14 +1601,16 @@ __global__ __launch_bounds__(kDfThreads) void k_dsconv_fused(const float* __rest
     if (threadIdx.x < 2 * groups) gst[threadIdx.x] = (threadIdx.x & 1) ? 1.f : 0.f;
     __syncthreads();
   } else {
-    channel_reduce(false);
-    channel_reduce(true);
+    channel_reduce(std::integral_constant<bool, false>{});
+    channel_reduce(std::integral_constant<bool, true>{});
   }
   // ---- y = GELU(GroupNorm(z)): 16-byte stores where the row allows it ----
   const bool vec = (To & 3) == 0;
+  int fq_e = fq;  // a fresh opaque copy of the lane's channel coordinate: hipcc otherwise keeps the ten channel indices of the bias
+  asm volatile("" : "+v"(fq_e));  // section alive (as 64-bit pairs) through the statistics and spills them in the sixteen-wave form
 #pragma unroll
   for (int ct = 0; ct < CT; ++ct) {
-    const int co = 16 * ct + fq;
+    const int co = 16 * ct + fq_e;
     if (co >= Co) continue;
     const float mu = gst[2 * (co / cpg)], rs = gst[2 * (co / cpg) + 1], w = gw[co], bb = gb[co];
     float* yr = y + ((size_t)b * Co + co) * To;
@@ -2769,12 +2779,18 @@ int edtts_dsconv_forward(const float* x, const float* dw, const float* pw, const
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
     const int lds = dsconv_fused_lds_floats<5, 10>() * (int)sizeof(float);
-    auto kern = k_dsconv_fused<5, 10, 4>;
+    auto kern = k_dsconv_fused<5, 10, 4, kDfT>;
+    auto kern_wide = k_dsconv_fused<5, 10, 2, kDfTWide>;
     if (dev >= 0 && dev < 64 && !attr_done[dev]) {
       HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+      HIP_TRY(hipFuncSetAttribute((const void*)kern_wide, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
       attr_done[dev] = true;
     }
-    hipLaunchKernelGGL(kern, dim3(B), dim3(kDfThreads), lds, st, x, dw, pw, pb, gn_w, gn_b, C_in, C_out, T, To, ksize, stride, groups, y);
+    static const bool no_wide = [] { const char* e = getenv("EDTTS_DSCONV_WAVES8"); return e && e[0] == '1'; }();  // (A/B hook)
+    if (!no_wide && stride == 1 && kDfTWide - 1 + ksize <= kDfXld)  // (measured and rejected: taps read straight from global memory instead of the staging tile, 85 vs 77.5 us)
+      hipLaunchKernelGGL(kern_wide, dim3(B), dim3(kDfTWide * 4), lds, st, x, dw, pw, pb, gn_w, gn_b, C_in, C_out, T, To, ksize, stride, groups, y);
+    else
+      hipLaunchKernelGGL(kern, dim3(B), dim3(kDfT * 4), lds, st, x, dw, pw, pb, gn_w, gn_b, C_in, C_out, T, To, ksize, stride, groups, y);
     LAUNCH_CHECK("k_dsconv_fused");
     return EDTTS_OK;
   }

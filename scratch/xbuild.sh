@@ -11,6 +11,6 @@ sys.path.insert(0,'/root/repo')
 import __graft_entry__ as g
 res=g.kernel_resources(open('/tmp/xb/build.log').read())
 for k,v in res.items():
-    if ('k_layer' in k or 'k_prologue' in k):
+    if ("k_layer" in k or "k_prologue" in k or "dsconv_fused" in k):
         print(k[:80], v)
 PY
