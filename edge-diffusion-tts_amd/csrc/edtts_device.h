@@ -24,7 +24,7 @@
 #if !defined(EDTTS_EXPERIMENTS) && (                                                                                               \
     defined(EDTTS_ABLATE_QKVSTORES) || defined(EDTTS_ABLATE_KVLOADS) || defined(EDTTS_DIAG) || defined(EDTTS_KV2) ||                \
     defined(EDTTS_PERSIST) || defined(EDTTS_H_DMA) || defined(EDTTS_SPLITLOAD) || defined(EDTTS_STAMPS) || defined(EDTTS_DS_ABL) || \
-    defined(EDTTS_FAST_BUILD) || defined(EDTTS_W2) || defined(EDTTS_WAVELOG) || defined(EDTTS_RB) || defined(EDTTS_WMAX) ||        \
+    defined(EDTTS_FAST_BUILD) || defined(EDTTS_W2) || defined(EDTTS_WAVELOG) || defined(EDTTS_PIN_MASK) || defined(EDTTS_RB) || defined(EDTTS_WMAX) ||        \
     defined(EDTTS_NF_DEFAULT) || defined(EDTTS_NF_FFN) || defined(EDTTS_STAMP_THREAD) || defined(EDTTS_STAMP_HEAD) ||               \
     defined(EDTTS16_ABLATE_BARRIER) || defined(EDTTS16_ABLATE_DMA) || defined(EDTTS16_SPLIT_BUILD) || defined(EDTTS16_PHASES) ||    \
     defined(EDTTS16_NF) || defined(EDTTS16_CTX_F32) || defined(EDTTS16_WIDE_KD_SELF) || defined(EDTTS16_WIDE_KD) ||                 \
@@ -33,6 +33,13 @@
 #error "tuning / ablation / diagnostic / measured-and-rejected variant switches are scratch-only: add -DEDTTS_EXPERIMENTS"
 #endif
 
+#ifndef EDTTS_PIN_MASK
+// Instruction types that may cross the scheduling pin IN FRONT of a K / V^T re-request inside an MFMA run (the pin behind it stays
+// total).  0x4 = SALU: the request's address arithmetic (7-12 scalar instructions per burst) then sits in the shadow of the run's
+// first MFMAs instead of in a clump between two MFMA groups whose excess over one MFMA's 32 cycles is exposed.  Round 4, same
+// device, three interleaved runs: 0.9084 vs 0.9140 ms per layer launch (0: round 3's total pin).  Results bitwise unchanged.
+#define EDTTS_PIN_MASK 0x4
+#endif
 #ifndef EDTTS_W2
 #define EDTTS_W2 0  // measured and rejected (round 4): the default decoder's 32-frame instance at TWO waves per SIMD (<= 256 registers: attention outputs wait in LDS for one projection over all heads, residual through global memory, no AGPR-class pins)
 #endif
@@ -756,7 +763,7 @@ EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, cons
         // the 40-MFMA run instead of one burst of 6 behind it): the group the next step needs FIRST is in flight ~1 000 cycles
         // longer.  PMC: s_waitcnt took 6 % of the wave's cycles, most of it here (profiles/r03_diag_phases.txt).
         qk(fold_tag, q, c, KA, qa, qr, S, NM, nm, [&](int a) {
-          __builtin_amdgcn_sched_barrier(0);
+          __builtin_amdgcn_sched_barrier(EDTTS_PIN_MASK);
           load_k_group(q, hd, cnext, KA, a);
           __builtin_amdgcn_sched_barrier(0);
         });
@@ -857,7 +864,7 @@ EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, cons
 #pragma unroll
               for (int ft = 0; ft < QT; ++ft) O[dt][QT * hf + ft] = EDTTS_MFMA(VA.v[t][dt][r], P[t][ft][r], O[dt][QT * hf + ft]);
 #if EDTTS_SPLIT_ON
-          __builtin_amdgcn_sched_barrier(0);
+          __builtin_amdgcn_sched_barrier(EDTTS_PIN_MASK);
           load_v_tile(q, hd, cnext, VA, t);  // this key tile's V^T fragments have been read: re-request them now
           __builtin_amdgcn_sched_barrier(0);
 #endif
