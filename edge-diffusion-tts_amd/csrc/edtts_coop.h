@@ -34,8 +34,8 @@ struct Coop {
   static constexpr int X_BYTES = HT * NF * 1024;                       // one GEMM output tile in register layout
   static constexpr int TILE_BYTES = A_BYTES + X_BYTES;
   static constexpr int LDS_BYTES = TILES * TILE_BYTES;
+  static constexpr bool FITS = LDS_BYTES * (4 / W) <= 160 * 1024;  // four waves per CU: 4 / W blocks (hidden 256: 32-frame tiles x 2 waves would need two 96-KiB blocks: not offered)
   static_assert(W == 2 || W == 4, "waves per tile");
-  static_assert(LDS_BYTES <= 160 * 1024, "cooperative tile state must fit the CU's LDS");
 };
 
 // acc_a (and acc_b) += sum over KT k-steps of frag(k) * bop(k): the n-split building block.  Fragments come straight from the
@@ -392,6 +392,7 @@ template <class C, int TAIL, int W>
 __global__ __launch_bounds__(64 * W) void k_layer_co(KArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_co[];
   using CO = Coop<C, W>;
+  static_assert(CO::FITS, "cooperative tile state must fit the CU's LDS");
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int tpu = a.Tp / C::WF, ntiles = a.B * tpu;

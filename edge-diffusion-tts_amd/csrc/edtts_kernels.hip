@@ -1901,11 +1901,15 @@ struct Launcher {
   //     4 t32 <= SIMDs   32-frame tiles, four waves each
   //     2 t32 <= SIMDs   32-frame tiles, two waves each       (B = 32, T = 512: 1024 waves that keep k_layer's 8 MFMAs per fragment)
   //     else             k_layer, one wave per 32-frame tile
-  static constexpr bool HAS_COOP = C::NF == 2 && C::H == 160 && C::HEADS == 4 && !SPLIT;
+  static constexpr bool HAS_COOP = C::NF == 2 && !SPLIT && ((C::H == 160 && C::HEADS == 4) || (C::H == 256 && C::HEADS == 8)) && C::MEL == 80;
+  static constexpr bool HAS_CO22 = HAS_COOP && Coop<C, 2>::FITS;
   static int coop_choice(int B, int Tp) {  // 0: none; 14: NF 1, W 4; 24: NF 2, W 4; 22: NF 2, W 2
-    if (g_coop >= 0) return g_coop;  // (edtts_set_coop: 0 switches the cooperative kernel off, 14 / 24 / 22 force an instance)
-    const int t32 = B * (Tp / 32), slots = wave_slots();
-    return 8 * t32 <= slots ? 14 : (4 * t32 <= slots ? 24 : (2 * t32 <= slots ? 22 : 0));
+    int co = g_coop;  // (edtts_set_coop: 0 switches the cooperative kernel off, 14 / 24 / 22 force an instance)
+    if (co < 0) {
+      const int t32 = B * (Tp / 32), slots = wave_slots();
+      co = 8 * t32 <= slots ? 14 : (4 * t32 <= slots ? 24 : (2 * t32 <= slots ? 22 : 0));
+    }
+    return (co == 22 && !HAS_CO22) ? 0 : co;
   }
   // one decoder forward given conditioning rows + context cache already in the workspace
   using DdpmStep = DdpmStepArgs;
@@ -1919,7 +1923,9 @@ struct Launcher {
       const int co = coop_choice(B, ws.Tp);
       if (co == 14) return Launcher<Small>::template forward<4>(lo, blob, ws, wsb, B, T, S, window, x, cond_row, cond_bstride, tail, eps, x_prev, x0, coef, st, ddpm, lms, vp);
       if (co == 24) return forward<4>(lo, blob, ws, wsb, B, T, S, window, x, cond_row, cond_bstride, tail, eps, x_prev, x0, coef, st, ddpm, lms, vp);
-      if (co == 22) return forward<2>(lo, blob, ws, wsb, B, T, S, window, x, cond_row, cond_bstride, tail, eps, x_prev, x0, coef, st, ddpm, lms, vp);
+      if constexpr (HAS_CO22) {
+        if (co == 22) return forward<2>(lo, blob, ws, wsb, B, T, S, window, x, cond_row, cond_bstride, tail, eps, x_prev, x0, coef, st, ddpm, lms, vp);
+      }
     }
     // Small grids: with 32 frames per wave fewer waves than SIMDs would be launched (B = 32 at T = 512: 512 waves for 1024 SIMDs;
     // B = 1: 8) -- the 16-frames-per-wave instance doubles the number of waves.  Same arithmetic per frame, bitwise.
@@ -2047,7 +2053,7 @@ struct Launcher {
 #define EDTTS_CO_ATTRS(CC, WW) EDTTS_CO_ATTR(CC, WW, TAIL_QKV); EDTTS_CO_ATTR(CC, WW, TAIL_EPS); EDTTS_CO_ATTR(CC, WW, TAIL_DDIM); EDTTS_CO_ATTR(CC, WW, TAIL_DDPM); EDTTS_CO_ATTR(CC, WW, TAIL_LMS); EDTTS_CO_ATTR(CC, WW, TAIL_VPRED)
       EDTTS_CO_ATTRS(Small, 4);
       EDTTS_CO_ATTRS(C, 4);
-      EDTTS_CO_ATTRS(C, 2);
+      if constexpr (HAS_CO22) { EDTTS_CO_ATTRS(C, 2); }
 #undef EDTTS_CO_ATTRS
 #undef EDTTS_CO_ATTR
     }

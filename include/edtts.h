@@ -271,7 +271,8 @@ int edtts_set_substreams(int n);
  * A decoder forward whose 32-frame tiles number at most half of the device's SIMDs (B * ceil(T/32) <= 2 * #CUs: B <= 32 at
  * T = 512, and the reference's B = 1 calls) runs its transformer layers with 2 or 4 waves per frame tile (csrc/edtts_coop.h:
  * attention split by heads, GEMMs by output tiles, exchanged through LDS) instead of one; the instance is chosen from the tile
- * count.  Results are bitwise those of the one-wave kernels.  Compiled for the default decoder (hidden 160, heads 4, n_mels 80, fp32).
+ * count.  Results are bitwise those of the one-wave kernels.  Compiled for the fp32 decoders (160, 4, 80) and (256, 8, 80; without the
+ * 32-frame x 2 form, whose tile state does not fit a CU twice).
  * mode: -1 automatic (default; environment EDTTS_COOP at load time), 0 off, 14 / 24 / 22 force (16-frame tiles x 4 waves,
  * 32-frame tiles x 4 waves, 32-frame tiles x 2 waves) -- for tests and measurements.  Returns the previous mode; other values
  * only query. */
