@@ -1378,16 +1378,17 @@ def test_bench_two_ranks_rehearsal():
     env = dict(os.environ, EDTTS_BENCH_REHEARSAL="1")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "EDTTS_BENCH_STUB"):
         env.pop(k, None)
-    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "8",
+    # (128 utterances per rank: large enough for the two-stream cut of the sampler call, so the all-gather follows a forked / joined call)
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "128",
                         "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["steps"] == 2 and d["scaling"] == "weak"
-    assert d["allgather_ms"] > 0 and d["allgather_bytes"] == 2 * 8 * 512 * 80 * 4
-    assert d["config"]["batch_per_gpu"] == 8 and "REHEARSAL" in d["note"]
-    assert abs(d["value"] - 2 * 8 * 512 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    assert d["allgather_ms"] > 0 and d["allgather_bytes"] == 2 * 128 * 512 * 80 * 4
+    assert d["config"]["batch_per_gpu"] == 128 and d["config"]["substreams"] == 2 and "REHEARSAL" in d["note"]
+    assert abs(d["value"] - 2 * 128 * 512 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
 
 
 def test_build_time_instance_192_6_80_vs_oracle():
