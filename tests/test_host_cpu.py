@@ -344,3 +344,28 @@ def test_pinned_workspaces_can_be_released(monkeypatch):
     assert len(dec._pinned_workspaces) == dec.WORKSPACE_CACHE + 1 and any("pinned" in str(x.message) for x in w)
     assert dec.release_pinned(B=1) == 1 and dec.release_pinned() == dec.WORKSPACE_CACHE
     assert not dec._pinned_workspaces and not dec._workspaces
+
+
+def test_run_time_switches_and_scratch_query_need_no_gpu():
+    """The library's host-only entry points: the two run-time switches return the previous value and ignore values outside their
+    domain; edtts_dsconv_scratch_floats says which shapes run as one kernel (no scratch) -- the stride / kernel-size condition of
+    include/edtts.h; the workspace query covers the sub-batch form of a sampler call (never smaller than the one-piece form)."""
+    L = native.lib()
+    prev = L.edtts_set_substreams(1)
+    assert L.edtts_set_substreams(0) == 1 and L.edtts_set_substreams(99) == 1  # queries: unchanged
+    assert L.edtts_set_substreams(2) == 1 and L.edtts_set_substreams(prev) == 2
+    prevc = L.edtts_set_coop(0)
+    assert L.edtts_set_coop(7) == 0 and L.edtts_set_coop(22) == 0 and L.edtts_set_coop(-1) == 22
+    L.edtts_set_coop(prevc)
+    need = ctypes.c_size_t(123)
+    L.edtts_dsconv_scratch_floats(4, 80, 160, 512, 3, 1, 8, ctypes.byref(need))
+    assert need.value == 0                                    # the reference's shape class: one kernel
+    L.edtts_dsconv_scratch_floats(4, 80, 160, 512, 3, 2, 8, ctypes.byref(need))
+    assert need.value == 0                                    # 127 * 2 + 3 <= 260
+    L.edtts_dsconv_scratch_floats(4, 80, 160, 512, 3, 3, 8, ctypes.byref(need))
+    assert need.value == 4 * 160 * 171 + 2 * 4 * 8            # stride 3: the three-kernel path, T_out = (512 + 2 - 3) // 3 + 1
+    L.edtts_dsconv_scratch_floats(4, 96, 160, 512, 3, 1, 8, ctypes.byref(need))
+    assert need.value == 4 * 160 * 512 + 2 * 4 * 8            # more input channels than the fused kernel holds
+    dec = EdgeDiffusionDecoder(CFG(device="cpu"))
+    a, b = native.workspace_bytes(dec.dims(), 255, 512, 256, 4), native.workspace_bytes(dec.dims(), 256, 512, 256, 4)
+    assert b > a > 255 * 512 * 160 * 4 * 7                    # h + two sets of q, k, v^T at least
