@@ -1329,16 +1329,20 @@ def test_substreams_do_not_change_results():
         native.set_substreams(prev)
 
 
-@pytest.mark.parametrize("B,S,window,hidden", [(1, 128, 64, 160), (3, 37, 64, 160), (2, 256, 64, 160), (1, 48, 37, 160), (5, 16, None, 160),
-                                                (2, 45, 64, 256)])
-def test_cooperative_instances_equal_the_one_wave_ones(B, S, window, hidden):
+@pytest.mark.parametrize("B,S,window,hidden,ffn_mult", [(1, 128, 64, 160, 2), (3, 37, 64, 160, 2), (2, 256, 64, 160, 2), (1, 48, 37, 160, 2),
+                                                         (5, 16, None, 160, 2), (2, 45, 64, 256, 2), (2, 40, 64, 160, 1), (1, 70, 64, 160, 3),
+                                                         (2, 33, 64, 160, 4)])
+def test_cooperative_instances_equal_the_one_wave_ones(B, S, window, hidden, ffn_mult):
     """Small grids run the transformer layers with 2 or 4 waves per frame tile (csrc/edtts_coop.h; chosen from the tile count,
     include/edtts.h: edtts_set_coop).  The split is by heads and by OUTPUT tiles only, so no sum changes: every forced instance
     (16-frame tiles x 4 waves, 32-frame tiles x 4 and x 2 waves -- the latter with an odd tile count: a block's surplus tile) must
     equal the one-wave kernels bitwise, for the eps tail (decoder forward), the fused DDIM tail (generate_mel), the DDPM tail with
     in-kernel noise and the multistep-solver tail; and the automatic choice must be one of them."""
     from edge_diffusion_tts_amd import DPMSolverPP, native
-    cfg = CFG(device=DEV, attn_window_size=window) if hidden == 160 else CFG(device=DEV, attn_window_size=window, hidden=256, heads=8, layers=2)
+    # (ffn_mult 1 / 3 / 4: the FFN's hidden tiles pass through LDS in groups of 2 * hidden / 16 -- a short only group, a full group + a
+    # short one, two full groups)
+    cfg = (CFG(device=DEV, attn_window_size=window, ffn_mult=ffn_mult) if hidden == 160 else
+           CFG(device=DEV, attn_window_size=window, hidden=256, heads=8, layers=2))
     dec = make_decoder(cfg, 3)  # (hidden 256: 16- and 32-frame tiles x 4 waves; 32-frame x 2 does not fit its LDS twice per CU and falls back)
     sch = DiffusionSchedule(cfg.diff_steps).to(DEV)
     infer = EdgeInference(cfg, sch, torch.nn.Identity(), dec)
