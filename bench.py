@@ -183,8 +183,8 @@ def main():
     ap.add_argument("--dtype", default=None, choices=("f32", "bf16"))
     ap.add_argument("--batch", type=int, default=None, help="utterances per GPU (default: the config's)")
     ap.add_argument("--frames", type=int, default=None, help="mel frames per utterance (T = 2*S)")
-    ap.add_argument("--substreams", type=int, default=None, choices=(1, 2, 3, 4),
-                    help="sub-batches of a sampler call on two streams (include/edtts.h: edtts_set_substreams); default: the library's (2)")
+    ap.add_argument("--substreams", type=int, default=None, choices=(1, 2, 3, 4, 5, 6, 7, 8),
+                    help="most sub-batches (streams) a sampler call may be cut into (include/edtts.h: edtts_set_substreams); default: the library's (4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -279,9 +279,10 @@ def main():
             native.set_substreams(1)  # counters per k_layer launch: launches must not share the device
         elif args.substreams is not None:
             native.set_substreams(args.substreams)
-        substreams = native.set_substreams(0)  # (0 only queries)
+        substreams_max = native.set_substreams(0)  # (0 only queries)
+        substreams = native.substreams_for(dec.dims(), B, T) if C["sampler"] != "none" else 1
     else:
-        substreams = 1
+        substreams_max = substreams = 1
     if C["sampler"] == "ddpm":
         # BASELINE config 5: the whole 1000-step ancestral sampler captured ONCE as a hipGraph; a step = one replay.  The start
         # noise is drawn into the graph's static input buffer inside the timed step.
@@ -380,7 +381,7 @@ def main():
         "config": {"workload": f"BASELINE config {args.config}: {what}, decoder hidden={H} L={L} heads={cfg.heads} n_mels={M} window={W}, "
                                f"B={B}/GPU T={T} S={S}, synthetic weights + tokens, start noise drawn inside the timed call",
                    "batch_per_gpu": B, "frames": T, "sampler_steps": C["num_steps"],
-                   "substreams": substreams,  # 2: batches of >= 2 rounds of waves run as two half-batches on two streams (edtts.h)
+                   "substreams": substreams,  # sub-batches (streams) this call shape is cut into (edtts.h: edtts_set_substreams; 1 = one piece)
                    "parallelism": (f"batch-sharded x{world}, all-gather of the final mel batch" + (f" overlapped with compute in {micro} slices" if micro > 1 else ""))
                    if world > 1 else "single GPU"},
         "mels_per_s": world * B / (dt / steps),
@@ -420,7 +421,7 @@ def main():
         torch.cuda.synchronize(dev)
         (ms0, n0), (ms1, n1) = native.profile_collect()
         native.profile_enable(0)
-        native.set_substreams(substreams)
+        native.set_substreams(substreams_max)
         frames = B * T
         fl_layer = frames * sum(layer_flops_per_frame(H, M, S, T, W, l == L - 1) for l in range(L)) / L  # mean over the L launches
         avg = (ms0 + ms1) / max(n0, 1)

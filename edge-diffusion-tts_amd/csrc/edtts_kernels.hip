@@ -1706,7 +1706,7 @@ static int device_simds() {
 // half's waves fill the SIMDs the other half's finishing launch leaves idle.  Each half is an ordinary call on its own slice
 // of the caller's workspace; results do not depend on the cut (every utterance is computed alone, bitwise).
 // ---------------------------------------------------------------------------------------------------------
-constexpr int kMaxSub = 4;
+constexpr int kMaxSub = 8;
 struct SubBatches {
   int n;                 // 1 (no cut) or 2
   int B[kMaxSub], off[kMaxSub];
@@ -1716,7 +1716,7 @@ struct SubBatches {
   size_t total;          // floats
 };
 static int g_coop = [] { const char* e = getenv("EDTTS_COOP"); return e ? atoi(e) : -1; }();
-static int g_substreams = [] { const char* e = getenv("EDTTS_SUBSTREAMS"); const int v = e ? atoi(e) : 2; return v < 1 ? 1 : (v > kMaxSub ? kMaxSub : v); }();
+static int g_substreams = [] { const char* e = getenv("EDTTS_SUBSTREAMS"); const int v = e ? atoi(e) : 4; return v < 1 ? 1 : (v > kMaxSub ? kMaxSub : v); }();
 
 static void plan_sub(const Layout& lo, int B, int T, int S, int cond_rows, int n, SubBatches* sb) {
   sb->n = n;
@@ -1738,15 +1738,23 @@ static void plan_sub(const Layout& lo, int B, int T, int S, int cond_rows, int n
   sb->cond = o;
   sb->total = align64(o + (size_t)cond_rows * lo.L * 2 * 2 * lo.H + (size_t)cond_rows * lo.H);
 }
-// the cut a sampler call makes: two halves when each still fills every SIMD at least once
-static void plan_call(const Layout& lo, int B, int T, int S, int cond_rows, float* wsb, SubBatches* sb) {
+// The cut a sampler call makes: as many sub-batches (at most g_substreams) as still leave each one TWO rounds of waves -- measured:
+// B=256, T=1024 bf16 (8 rounds) 33.0 ms at two, 31.8 at four, 32.7 at six, 33.0 at eight; B=512, T=512 fp32 (8 rounds) 30.37 at two,
+// 30.31 at four; B=256, T=512 fp32 (4 rounds) the same at two and four -- but two halves of ONE round each where the batch has only two
+// rounds (B=128, T=512 fp32: 7.88 ms in one piece, 7.74 cut).
+static int substreams_for(const Layout& lo, int B, int T, int S) {
   Workspace w;
   make_workspace(lo, 1, T, S, 1, &w);
-  const long waves = (long)B * (w.Tp / 32);
-  // (n halves as long as each still fills every SIMD at least once)
-  int n = g_substreams;
-  while (n > 1 && (B < n || waves < (long)n * device_simds())) --n;
-  plan_sub(lo, B, T, S, cond_rows, n, sb);
+  const long waves = (long)B * (w.Tp / 32), slots = device_simds();
+  if (g_substreams < 2 || B < 2 || waves < 2 * slots) return 1;
+  long n = waves / (2 * slots);
+  if (n < 2) n = 2;
+  if (n > g_substreams) n = g_substreams;
+  if (n > B) n = B;
+  return (int)n;
+}
+static void plan_call(const Layout& lo, int B, int T, int S, int cond_rows, float* wsb, SubBatches* sb) {
+  plan_sub(lo, B, T, S, cond_rows, substreams_for(lo, B, T, S), sb);
   for (int j = 0; j < sb->n; ++j) sb->ws[j].errp = reinterpret_cast<unsigned*>(wsb);
 }
 
@@ -2924,6 +2932,12 @@ int edtts_set_substreams(int n) {
   const int prev = g_substreams;
   if (n >= 1 && n <= kMaxSub) g_substreams = n;
   return prev;
+}
+
+int edtts_substreams_for(const EdttsDims* dims, int B, int T) {
+  Layout lo;
+  if (make_layout(dims, &lo) || B < 1 || T < 1) return 1;
+  return substreams_for(lo, B, T, (T + 1) / 2);
 }
 
 int edtts_profile_enable(int max_records) {

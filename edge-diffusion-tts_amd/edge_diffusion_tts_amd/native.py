@@ -20,7 +20,7 @@ EXPORTED_SYMBOLS = (
     "edtts_layer_slot_name", "edtts_packed_bytes", "edtts_pack_weights", "edtts_workspace_bytes", "edtts_decoder_forward",
     "edtts_ddim_step", "edtts_ddpm_step", "edtts_generate", "edtts_sample_ddpm", "edtts_sample_multistep", "edtts_dsconv_forward", "edtts_profile_enable",
     "edtts_profile_collect", "edtts_randn", "edtts_index_errors", "edtts_sample_inpaint",
-    "edtts_mel_to_spec", "edtts_griffin_lim_scratch_floats", "edtts_griffin_lim", "edtts_set_substreams", "edtts_set_coop", "edtts_dsconv_scratch_floats",
+    "edtts_mel_to_spec", "edtts_griffin_lim_scratch_floats", "edtts_griffin_lim", "edtts_set_substreams", "edtts_set_coop", "edtts_dsconv_scratch_floats", "edtts_substreams_for",
 )
 
 
@@ -84,10 +84,12 @@ def lib() -> C.CDLL:
     L.edtts_set_substreams.restype = i32
     L.edtts_set_coop.argtypes = [i32]
     L.edtts_set_coop.restype = i32
+    L.edtts_substreams_for.argtypes = [C.POINTER(EdttsDims), i32, i32]
+    L.edtts_substreams_for.restype = i32
     L.edtts_profile_collect.argtypes = [C.POINTER(C.c_double), C.POINTER(i32)]  # arrays of 2
     for name in EXPORTED_SYMBOLS:
         fn = getattr(L, name)
-        if fn.restype is C.c_int and name not in ("edtts_version", "edtts_num_global_slots", "edtts_num_layer_slots", "edtts_set_substreams", "edtts_set_coop"):
+        if fn.restype is C.c_int and name not in ("edtts_version", "edtts_num_global_slots", "edtts_num_layer_slots", "edtts_set_substreams", "edtts_set_coop", "edtts_substreams_for"):
             fn.errcheck = _errcheck
     _lib = L
     return L
@@ -292,9 +294,14 @@ def check_table_index(t: torch.Tensor, n: int, name: str, lo: int = 0) -> None:
 
 
 def set_substreams(n: int) -> int:
-    """1: every sampler call runs its batch in one piece; 2 (default): large batches are cut into two halves on two streams
-    (include/edtts.h: edtts_set_substreams).  Returns the previous setting."""
+    """1: every sampler call runs its batch in one piece; n >= 2 (default 4): large batches are cut into up to n sub-batches on as many
+    streams (include/edtts.h: edtts_set_substreams).  Returns the previous setting."""
     return int(lib().edtts_set_substreams(int(n)))
+
+
+def substreams_for(dims: EdttsDims, B: int, T: int) -> int:
+    """Sub-batches a sampler call of this shape makes under the current setting."""
+    return int(lib().edtts_substreams_for(C.byref(dims), int(B), int(T)))
 
 
 def set_coop(mode: int) -> int:

@@ -16,7 +16,7 @@
  *     (a hipStream_t passed as void*; NULL = the null stream).  All calls are graph-capturable.
  *   - return value: 0 on success, a negative EDTTS_ERR_* otherwise; edtts_last_error() returns a
  *     thread-local message for the last failing call.
- *   - environment switches, read once per process: EDTTS_SUBSTREAMS=1|2 (see edtts_set_substreams, default 2);
+ *   - environment switches, read once per process: EDTTS_SUBSTREAMS=1..8 (see edtts_set_substreams, default 4);
  *     EDTTS_DSCONV_UNFUSED=1 forces the three-kernel conv path.
  */
 #ifndef EDTTS_H_
@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define EDTTS_VERSION 400 /* 0.4.0: sub-batches on two streams (edtts_set_substreams); the workspace grew accordingly */
+#define EDTTS_VERSION 400 /* 0.4.0: sub-batches on several streams (edtts_set_substreams); the workspace grew accordingly; cooperative kernels */
 
 enum {
   EDTTS_OK = 0,
@@ -257,15 +257,18 @@ int edtts_griffin_lim(const float* spec, int B, int T, int n_fft, int hop, const
 int edtts_profile_enable(int max_records);
 int edtts_profile_collect(double* ms_by_kind, int* launches_by_kind);
 
-/* ---- sub-batches on two streams ---------------------------------------------------------------------------
+/* ---- sub-batches on several streams -------------------------------------------------------------------------
  * The sampler loops (edtts_generate, edtts_sample_multistep, edtts_sample_ddpm) cut a batch whose layer launches are at least two
- * full rounds of one wave per SIMD (B * ceil(T/32) >= 2 * 4 * #CUs: B >= 128 at T = 512 on an MI355X) into two halves that walk
- * the same launch sequence on two streams -- `stream` and a library-owned non-blocking one, forked from and joined back into
- * `stream` with events inside the call (graph-capturable; the caller sees ordinary stream semantics) -- so that one half's waves
- * fill the SIMDs the other half's finishing launch leaves idle.  Results do not depend on the cut (bitwise).  n = 1 switches
- * the cut off (per-kernel profiling wants launches that do not share the device), n = 2 (the default; environment
- * EDTTS_SUBSTREAMS at load time) switches it on.  Returns the previous value; values outside [1, 2] only query. */
+ * full rounds of one wave per SIMD (B * ceil(T/32) >= 2 * 4 * #CUs: B >= 128 at T = 512 on an MI355X) into sub-batches that walk
+ * the same launch sequence on several streams -- `stream` and library-owned non-blocking ones, forked from and joined back into
+ * `stream` with events inside the call (graph-capturable; the caller sees ordinary stream semantics) -- so that one sub-batch's
+ * waves fill the SIMDs another's finishing launch leaves idle.  How many: as many as still leave each sub-batch two rounds of
+ * waves, at least two, at most n (B = 256: two at T = 512, four at T = 1024).  Results do not depend on the cut (bitwise).
+ * n = 1 switches the cut off (per-kernel profiling wants launches that do not share the device); the default is 4 (environment
+ * EDTTS_SUBSTREAMS at load time), the maximum 8.  Returns the previous value; values outside [1, 8] only query.
+ * edtts_substreams_for: the number of sub-batches a call of that shape makes under the current setting. */
 int edtts_set_substreams(int n);
+int edtts_substreams_for(const EdttsDims* dims, int B, int T);
 
 /* ---- small grids: the cooperative layer kernel ---------------------------------------------------------------
  * A decoder forward whose 32-frame tiles number at most half of the device's SIMDs (B * ceil(T/32) <= 2 * #CUs: B <= 32 at

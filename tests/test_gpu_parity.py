@@ -1325,6 +1325,14 @@ def test_substreams_do_not_change_results():
         infer.generate_mel(bad, 4, x_T=x)
         ws = dec.workspace(B, 2 * S, S, 4, x.device)
         assert native.index_errors(ws) == 1 and native.index_errors(ws) == 0
+        # three sub-batches (385 utterances = 6160 waves: two rounds each allow three; 129 + 128 + 128) against one piece
+        native.set_substreams(4)
+        B3 = 385
+        assert native.substreams_for(dec.dims(), B3, 2 * S) == 3
+        sem3 = torch.randint(0, 512, (B3, S), generator=gen).to(DEV)
+        three = infer.generate_mel(sem3, 2, seed=21)
+        native.set_substreams(1)
+        assert torch.equal(three, infer.generate_mel(sem3, 2, seed=21))
     finally:
         native.set_substreams(prev)
 

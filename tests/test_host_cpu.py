@@ -357,6 +357,16 @@ def test_run_time_switches_and_scratch_query_need_no_gpu():
     prevc = L.edtts_set_coop(0)
     assert L.edtts_set_coop(7) == 0 and L.edtts_set_coop(22) == 0 and L.edtts_set_coop(-1) == 22
     L.edtts_set_coop(prevc)
+    # how many sub-batches a call shape is cut into (1024 SIMDs assumed without a device): two rounds of waves each, at least two, at most the setting
+    d160, d256 = EdgeDiffusionDecoder(CFG(device="cpu")).dims(), EdgeDiffusionDecoder(CFG(hidden=256, heads=8, layers=8, device="cpu"), max_len=1024).dims()
+    old = L.edtts_set_substreams(4)
+    assert [native.substreams_for(d160, b, 512) for b in (1, 64, 127, 128, 256, 384, 512, 2048)] == [1, 1, 1, 2, 2, 3, 4, 4]
+    assert native.substreams_for(d256, 256, 1024) == 4 and native.substreams_for(d160, 256, 1000) == 4 and native.substreams_for(d160, 3, 99999) == 3
+    L.edtts_set_substreams(2)
+    assert native.substreams_for(d160, 512, 512) == 2
+    L.edtts_set_substreams(1)
+    assert native.substreams_for(d160, 512, 512) == 1
+    L.edtts_set_substreams(old)
     need = ctypes.c_size_t(123)
     L.edtts_dsconv_scratch_floats(4, 80, 160, 512, 3, 1, 8, ctypes.byref(need))
     assert need.value == 0                                    # the reference's shape class: one kernel
