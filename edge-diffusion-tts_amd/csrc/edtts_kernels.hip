@@ -453,10 +453,29 @@ EDTTS_DEV TileId wave_tile(int B, int Tp, int waves_per_block, int wave_frames) 
 // QKV of one layer from the normalised tile hn: stores q, k row-major [B][Tp][H] and v transposed [B][VR][Tp]
 // (layers/attention.py:91-93: rows of qkv.weight are q | k | v, each head-major)
 // ---------------------------------------------------------------------------------------------------------
+#ifndef EDTTS_TAIL_RING2
+#define EDTTS_TAIL_RING2 1  // round 4, same device, three interleaved runs: k_layer 0.9084-0.9121 ms against 0.9133-0.9165 with the kernel's own ring (0)
+#endif
 template <class C>
-EDTTS_DEV void qkv_tail(WStream<C>& ring, const f4 (&hn)[C::HT][C::NF], const KArgs& a, int b, int m0, int lane) {
+EDTTS_DEV void qkv_tail(WStream<C>& ring0, const f4 (&hn)[C::HT][C::NF], const KArgs& a, int b, int m0, int lane) {
   constexpr int NF = C::NF;
   static_assert(C::HT % 2 == 0, "hidden must be a multiple of 32 (n-tile pairs)");
+#if EDTTS_TAIL_RING2
+  // The tail's stores sit in the same in-order vmcnt queue as the ring's loads: a fragment requested right behind a store burst cannot
+  // be consumed before the stores are acknowledged.  Nothing but the normalised tile is live here, so the tail runs on a ring of twice
+  // the length (twice the distance between a request and its use): the old ring's slots are its first half.
+  constexpr int RN0 = WStream<C>::RN_;
+  static_assert((2 * C::HT) % (2 * RN0) == 0, "a pair phase must be a whole number of turns of the doubled ring");
+  FragRing<2 * RN0> ring;
+  ring.rs = ring0.rs; ring.soff = ring0.soff; ring.voff = ring0.voff;
+#pragma unroll
+  for (int i = 0; i < RN0; ++i) ring.r[i] = ring0.at(i);
+#pragma unroll
+  for (int i = RN0; i < 2 * RN0; ++i) ring.r[i] = ring.frag(i);
+  __builtin_amdgcn_sched_barrier(0);
+#else
+  WStream<C>& ring = ring0;
+#endif
   const int fq = lane & 15, g = lane >> 4;
   const size_t rowbase = (size_t)b * a.Tp + m0 + fq;
   // One loop per output so that the number of stores between two ring waits is a compile-time fact of each loop: the
