@@ -2323,14 +2323,21 @@ struct Launcher16 {
 #define EDTTS_EXTRA_INSTANCES(lo, ...)
 #define EDTTS_EXTRA_NAMES ""
 #endif
+// ... and bf16 shapes (head_dim 32, hidden % 64 == 0: the bf16 kernels identify a head with one 32-wide k-tile): EDTTS_INSTANCES_BF16
+#ifndef EDTTS_EXTRA_INSTANCES16
+#define EDTTS_EXTRA_INSTANCES16(lo, ...)
+#define EDTTS_EXTRA_NAMES16 ""
+#endif
+#define EDTTS_X16(lo, HH, HD, MM, ...) else if ((lo).H == HH && (lo).HEADS == HD && (lo).MEL == MM) { using LN = Launcher16<edtts16::Cfg16<HH, HD, MM>>; __VA_ARGS__; }
 #define EDTTS_X(lo, HH, HD, MM, ...) else if ((lo).H == HH && (lo).HEADS == HD && (lo).MEL == MM) { using LN = Launcher<Cfg<HH, HD, MM>>; __VA_ARGS__; }
 #define EDTTS_DISPATCH(lo, ...)                                                                          \
   do {                                                                                                   \
     if ((lo).BF16) {                                                                                     \
       if ((lo).H == 256 && (lo).HEADS == 8 && (lo).MEL == 80) { using LN = Launcher16<edtts16::Cfg16<256, 8, 80, EDTTS16_NF>>; __VA_ARGS__; } \
       else if ((lo).H == 64 && (lo).HEADS == 2 && (lo).MEL == 80) { using LN = Launcher16<edtts16::Cfg16<64, 2, 80>>; __VA_ARGS__; } \
+      EDTTS_EXTRA_INSTANCES16(lo, __VA_ARGS__)                                                           \
       else return fail(EDTTS_ERR_UNSUPPORTED, "no bf16 kernel instance for hidden=%d heads=%d n_mels=%d "  \
-                       "(compiled: 256/8/80, 64/2/80)", (lo).H, (lo).HEADS, (lo).MEL);                     \
+                       "(compiled: 256/8/80, 64/2/80" EDTTS_EXTRA_NAMES16 "; more: EDTTS_INSTANCES_BF16 at build time)", (lo).H, (lo).HEADS, (lo).MEL); \
     }                                                                                                    \
     else if ((lo).H == 160 && (lo).HEADS == 4 && (lo).MEL == 80) { using LN = Launcher<Cfg<160, 4, 80, EDTTS_NF_DEFAULT>>; __VA_ARGS__; } \
     else if ((lo).H == 256 && (lo).HEADS == 8 && (lo).MEL == 80) { using LN = Launcher<Cfg<256, 8, 80>>; __VA_ARGS__; }     \

@@ -60,7 +60,8 @@ typedef struct EdttsDims {
   int32_t n_step_emb;    /* rows of step_emb           (decoder.py:32: 16)   */
   int32_t compute_dtype; /* EDTTS_F32: everything fp32 (the reference's arithmetic).  EDTTS_BF16: contractions on bf16 MFMA with
                             fp32 accumulation; residual stream, norms, softmax and sampler updates stay fp32 (the reference's AMP
-                            precedent: utils/speed_utils.py:70, train_v2.py:290).  Compiled for head_dim 32 (BASELINE config 3). */
+                            precedent: utils/speed_utils.py:70, train_v2.py:290).  head_dim 32 shapes only (hidden = 32 * heads, hidden % 64
+                            == 0): built in 256/8/80 (BASELINE config 3) and 64/2/80, more through EDTTS_INSTANCES_BF16 at build time. */
 } EdttsDims;
 
 enum { EDTTS_F32 = 0, EDTTS_BF16 = 1 };

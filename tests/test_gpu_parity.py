@@ -1434,3 +1434,36 @@ def test_build_time_instance_192_6_80_vs_oracle():
     bad = EdgeDiffusionDecoder(CFG(hidden=224, heads=7, device=DEV)).to(DEV).eval()
     with pytest.raises(native.EdttsError, match="192/6/80"):
         bad(torch.zeros(1, 32, 80, device=DEV), torch.zeros(1, dtype=torch.long, device=DEV), torch.zeros(1, 16, dtype=torch.long, device=DEV))
+
+
+def test_build_time_bf16_instance_128_4_80_vs_oracle():
+    """A bf16 decoder shape from the build-time list (EDTTS_INSTANCES_BF16 / __graft_entry__.DEFAULT_INSTANCES_BF16; head_dim 32
+    shapes only): forward against the fp32 CPU oracle at the bf16 tolerances, sampler properties, and a head_dim-40 bf16 request is
+    refused with a message that says why."""
+    import os
+    import __graft_entry__ as G
+    from edge_diffusion_tts_amd import native
+    if "128x4x80" not in os.environ.get("EDTTS_INSTANCES_BF16", G.DEFAULT_INSTANCES_BF16):
+        pytest.skip("this library was built without the bf16 128x4x80 instance")
+    cfg = CFG(hidden=128, heads=4, layers=3, device=DEV)
+    sd = synth_state_dict(cfg, 6)
+    dec = EdgeDiffusionDecoder(cfg, compute_dtype="bf16")
+    dec.load_state_dict(sd)
+    dec = dec.to(DEV).eval()
+    gen = torch.Generator().manual_seed(78)
+    B, S = 3, 53
+    sem = torch.randint(0, 512, (B, S), generator=gen)
+    x = torch.randn(B, 2 * S, 80, generator=gen)
+    t = torch.tensor([999, 420, 7])
+    si = torch.tensor([0, 5, 15])
+    e = dec(cu(x), cu(t), cu(sem), cu(si)).cpu()
+    ref = O.decoder_forward(sd, x, t, sem, si, heads=4)
+    print(f"bf16 128/4/80 instance, forward vs the fp32 oracle: rms {rms(e, ref):.2e} max {max_abs(e, ref):.2e}")
+    assert bool(torch.isfinite(e).all()) and rms(e, ref) < BF16_RMS_TOL and max_abs(e, ref) < BF16_MAX_TOL
+    infer = EdgeInference(cfg, DiffusionSchedule(cfg.diff_steps).to(DEV), torch.nn.Identity(), dec)
+    a = infer.generate_mel(cu(sem), 4, x_T=cu(x))
+    assert torch.equal(a, infer.generate_mel(cu(sem), 4, x_T=cu(x))) and float(a.abs().max()) <= 3.0
+    assert torch.equal(infer.generate_mel(cu(sem[1:2]).contiguous(), 4, x_T=cu(x[1:2]).contiguous())[0], a[1])
+    with pytest.raises(native.EdttsError, match="head_dim 32"):
+        bad = EdgeDiffusionDecoder(CFG(device=DEV), compute_dtype="bf16").to(DEV).eval()
+        bad(torch.zeros(1, 32, 80, device=DEV), torch.zeros(1, dtype=torch.long, device=DEV), torch.zeros(1, 16, dtype=torch.long, device=DEV))

@@ -322,6 +322,13 @@ def test_build_time_instance_list():
             G.instance_flags(bad)
     # the product build carries the default list, and the flags are part of the stale check
     assert all(x in G.FLAGS for x in G.instance_flags(os.environ.get("EDTTS_INSTANCES", G.DEFAULT_INSTANCES)))
+    # bf16 shapes: head_dim 32 and hidden % 64 == 0 only
+    f16 = G.instance_flags("128x4x80,256x8x80", bf16=True)
+    assert f16 == ["-DEDTTS_EXTRA_INSTANCES16(lo,...)=EDTTS_X16(lo,128,4,80,__VA_ARGS__)", '-DEDTTS_EXTRA_NAMES16=", 128/4/80"']
+    for bad in ("160x4x80", "96x3x80", "128x4x81", "128x8x80"):
+        with pytest.raises(ValueError):
+            G.instance_flags(bad, bf16=True)
+    assert all(x in G.FLAGS for x in G.instance_flags(os.environ.get("EDTTS_INSTANCES_BF16", G.DEFAULT_INSTANCES_BF16), bf16=True))
 
 
 def test_pinned_workspaces_can_be_released(monkeypatch):
