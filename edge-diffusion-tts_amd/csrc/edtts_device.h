@@ -24,7 +24,7 @@
 #if !defined(EDTTS_EXPERIMENTS) && (                                                                                               \
     defined(EDTTS_ABLATE_QKVSTORES) || defined(EDTTS_ABLATE_KVLOADS) || defined(EDTTS_DIAG) || defined(EDTTS_KV2) ||                \
     defined(EDTTS_PERSIST) || defined(EDTTS_H_DMA) || defined(EDTTS_SPLITLOAD) || defined(EDTTS_STAMPS) || defined(EDTTS_DS_ABL) || \
-    defined(EDTTS_FAST_BUILD) || defined(EDTTS_W2) || defined(EDTTS_WAVELOG) || defined(EDTTS_PIN_MASK) || defined(EDTTS_TAIL_RING2) || defined(EDTTS_RB) || defined(EDTTS_WMAX) ||        \
+    defined(EDTTS_FAST_BUILD) || defined(EDTTS_W2) || defined(EDTTS_WAVELOG) || defined(EDTTS_PIN_MASK) || defined(EDTTS_HANDOVER) || defined(EDTTS_TAIL_RING2) || defined(EDTTS_RB) || defined(EDTTS_WMAX) ||        \
     defined(EDTTS_NF_DEFAULT) || defined(EDTTS_NF_FFN) || defined(EDTTS_STAMP_THREAD) || defined(EDTTS_STAMP_HEAD) ||               \
     defined(EDTTS16_ABLATE_BARRIER) || defined(EDTTS16_ABLATE_DMA) || defined(EDTTS16_SPLIT_BUILD) || defined(EDTTS16_PHASES) ||    \
     defined(EDTTS16_NF) || defined(EDTTS16_CTX_F32) || defined(EDTTS16_WIDE_KD_SELF) || defined(EDTTS16_WIDE_KD) ||                 \
@@ -753,7 +753,7 @@ EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, cons
       }
       using Yes = std::integral_constant<bool, true>;
       using No = std::integral_constant<bool, false>;
-      auto step = [&](auto fold_tag, int c, int cnext, KVFrag<C>& KA, VFrag<C>& VA) {  // c: this step's chunk, cnext: the chunk to request into the buffers
+      auto step = [&](auto fold_tag, int c, int cnext, KVFrag<C>& KA, VFrag<C>& VA, int hd_req) {  // c: this step's chunk; (hd_req, cnext): the head and chunk to request into the buffers
         constexpr bool FOLD = decltype(fold_tag)::value;
 #ifdef EDTTS_STAMPS
         if (hd == STAMP_SEL_HEAD(stamp_sel)) STAMPX(stamps, sidx++, stamp_sel);
@@ -764,7 +764,7 @@ EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, cons
         // longer.  PMC: s_waitcnt took 6 % of the wave's cycles, most of it here (profiles/r03_diag_phases.txt).
         qk(fold_tag, q, c, KA, qa, qr, S, NM, nm, [&](int a) {
           __builtin_amdgcn_sched_barrier(EDTTS_PIN_MASK);
-          load_k_group(q, hd, cnext, KA, a);
+          load_k_group(q, hd_req, cnext, KA, a);
           __builtin_amdgcn_sched_barrier(0);
         });
         __builtin_amdgcn_sched_barrier(0);
@@ -772,7 +772,7 @@ EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, cons
         qk(fold_tag, q, c, KA, qa, qr, S, NM, nm, [](int) {});
         __builtin_amdgcn_sched_barrier(0);
 #ifndef EDTTS_ABLATE_KVLOADS  // timing ablation only
-        load_k(q, hd, cnext, KA);  // (the last step re-reads its own tiles)
+        load_k(q, hd_req, cnext, KA);  // (the last step re-reads its own tiles)
 #endif
         __builtin_amdgcn_sched_barrier(0);
 #endif
@@ -865,13 +865,13 @@ EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, cons
               for (int ft = 0; ft < QT; ++ft) O[dt][QT * hf + ft] = EDTTS_MFMA(VA.v[t][dt][r], P[t][ft][r], O[dt][QT * hf + ft]);
 #if EDTTS_SPLIT_ON
           __builtin_amdgcn_sched_barrier(EDTTS_PIN_MASK);
-          load_v_tile(q, hd, cnext, VA, t);  // this key tile's V^T fragments have been read: re-request them now
+          load_v_tile(q, hd_req, cnext, VA, t);  // this key tile's V^T fragments have been read: re-request them now
           __builtin_amdgcn_sched_barrier(0);
 #endif
         }
         __builtin_amdgcn_sched_barrier(0);
 #if !EDTTS_SPLIT_ON && !defined(EDTTS_ABLATE_KVLOADS)
-        load_v(q, hd, cnext, VA);
+        load_v(q, hd_req, cnext, VA);
 #endif
         __builtin_amdgcn_sched_barrier(0);
 #ifdef EDTTS_STAMPS
@@ -882,17 +882,30 @@ EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, cons
       const int cd = q.cdiag;
       auto chunk_of = [&](int st) { return st >= nchunk ? nchunk - 1 : (st == 0 ? cd : (st <= cd ? st - 1 : st)); };
 #if EDTTS_KV2
-      step(No{}, cd, chunk_of(2), KA, VA);
+      step(No{}, cd, chunk_of(2), KA, VA, hd);
       for (int st = 1; st < nchunk; st += 2) {
-        step(Yes{}, chunk_of(st), chunk_of(st + 2), KB, VB);
-        if (st + 1 < nchunk) step(Yes{}, chunk_of(st + 1), chunk_of(st + 3), KA, VA);
+        step(Yes{}, chunk_of(st), chunk_of(st + 2), KB, VB, hd);
+        if (st + 1 < nchunk) step(Yes{}, chunk_of(st + 1), chunk_of(st + 3), KA, VA, hd);
       }
 #else
       // (Requesting the NEXT head's first q / K / V^T tiles from the head's last step instead of from its projection phase -- so
       // that the phase's weight-ring waits do not queue behind HBM-latency requests in the in-order vmcnt -- was built and measured:
       // 0.9369 vs 0.9307 ms per launch, slower; the per-step q re-request it needs costs more than the phase gains.)
-      step(No{}, cd, chunk_of(1), KA, VA);
-      for (int st = 1; st < nchunk; ++st) step(Yes{}, chunk_of(st), chunk_of(st + 1), KA, VA);
+#ifndef EDTTS_HANDOVER
+#define EDTTS_HANDOVER 1
+#endif
+      // EDTTS_HANDOVER (round 4): a head's LAST step requests the NEXT head's first K / V^T tiles instead of re-reading its own -- the
+      // requests are issued anyway, and the next head starts on chunk cd too (same geometry) -- and only the q fragments are fetched
+      // from the projection phase: the phase's ring refills then queue behind 5 q requests (rows this XCD wrote: L2 hits) instead of 17
+      // HBM-latency ones in the in-order vmcnt.  Same device, three interleaved runs: k_layer 0.9014-0.9062 ms against 0.9150-0.9168, the
+      // whole call 15.02-15.09 against 15.26-15.31 ms; results bitwise unchanged.  (Round 3's attempt re-requested q in every step
+      // and lost 0.7 %.)
+      constexpr bool HANDOVER = EDTTS_HANDOVER && NHALF == 1;
+      const bool more = HANDOVER && hd + hstep < C::HEADS;
+      auto req_head = [&](int st) { return (more && st == nchunk - 1) ? hd + hstep : hd; };
+      auto req_chunk = [&](int st) { return (more && st == nchunk - 1) ? cd : chunk_of(st + 1); };
+      step(No{}, cd, req_chunk(0), KA, VA, req_head(0));
+      for (int st = 1; st < nchunk; ++st) step(Yes{}, chunk_of(st), req_chunk(st), KA, VA, req_head(st));
 #endif
       // normalise this half's rows
 #pragma unroll
@@ -907,7 +920,14 @@ EDTTS_DEV void attention_fused(QLoad&& qload, const float* __restrict__ Kb, cons
 #ifdef EDTTS_STAMPS
     if (hd == STAMP_SEL_HEAD(stamp_sel)) STAMPX(stamps, sidx++, stamp_sel);  // (normalisation done: start of the projection phases)
 #endif
-    if (hd + hstep < C::HEADS) prefetch(geo[0], hd + hstep, 0);
+    if (hd + hstep < C::HEADS) {
+      if constexpr (EDTTS_HANDOVER && NHALF == 1) {
+        load_q(hd + hstep, 0);  // (its K / V^T tiles were requested by the last step)
+        __builtin_amdgcn_sched_barrier(0);
+      } else {
+        prefetch(geo[0], hd + hstep, 0);
+      }
+    }
     if constexpr (OMODE != O_FUSED) {
       // this head's O^T tiles wait in LDS as they stand (C/D layout = the projection's B operand: lane-contiguous, conflict-free)
       char* ob = obuf + hd * C::OHEAD_BYTES;
