@@ -1460,8 +1460,9 @@ constexpr int kDfT = 128;  // frames per pass of the eight-wave form (any stride
 constexpr int kDfTWide = 256;  // ... of the sixteen-wave form (stride 1, ksize <= 5: 255 + ksize <= 260): four waves per SIMD (128 registers: the z
                                // tile of a wave is 80 of them) overlap one wave's staging, taps and stores with another's MFMAs -- round 4
 constexpr int kDfXld = 260;  // raw input frames per pass and channel: 127 * stride + ksize <= 260; 4 rows apart = 16 banks apart: the four lane groups of a depthwise read (rows 4 g + r) fall on disjoint banks
+constexpr int kDfTapLd = 5;   // depthwise taps per channel kept in LDS by the sixteen-wave form (ksize <= 5 there; odd = conflict-free over channels)
 template <int KT, int CT>
-constexpr int dsconv_fused_lds_floats() { return 16 * CT * (16 * KT + 4) + 16 * KT * kDfXld; }
+constexpr int dsconv_fused_lds_floats() { return 16 * CT * (16 * KT + 4) + 16 * KT * kDfXld + 16 * KT * kDfTapLd; }
 // erf(x) by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7 absolute, far inside the layer's 1e-5 budget): 1 rcp + 1 exp2 + 7 VALU
 // against ~35 instructions of the library erff -- the GELU of 21 M outputs is 19 us of chip-wide VALU time with the latter.
 EDTTS_DEV float erf_as(float x) {
@@ -1475,6 +1476,13 @@ EDTTS_DEV float erf_as(float x) {
   const float r = fmaf(-p * t, e, 1.0f);
   return copysignf(r, x);
 }
+#ifdef EDTTS_DS_STAMPS  // diagnostic build (-DEDTTS_EXPERIMENTS): s_memtime of wave 0 of every block at the phase boundaries of k_dsconv_fused
+__device__ unsigned long long g_ds_stamps[1024 * 16];
+#define DS_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 1024) g_ds_stamps[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+extern "C" int edtts_debug_read_ds_stamps(unsigned long long* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_ds_stamps), sizeof(g_ds_stamps)); }
+#else
+#define DS_STAMP(i) do { } while (0)
+#endif
 #ifndef EDTTS_DS_ABL
 #define EDTTS_DS_ABL 0   // timing ablations (-DEDTTS_EXPERIMENTS; results wrong): 1 no erf, 2 no stores, 4 no MFMAs, 8 no input staging, 16 no statistics
 #endif
@@ -1495,6 +1503,57 @@ __global__ __launch_bounds__(TP * 4) void k_dsconv_fused(const float* __restrict
     const int co = i / Cip, ci = i % Cip;
     wsm[co * WLD + ci] = (co < Co && ci < Ci) ? pw[(size_t)co * Ci + ci] : 0.f;
   }
+  // Sixteen-wave form (EDTTS_DS_BURST, round 4): a wave requests ALL its rows of a pass in one burst (its 5 channels x 5 segments
+  // are in flight together instead of three load -> LDS round trips), and the rows of pass p + 1 are requested BEFORE the taps and
+  // MFMAs of pass p and parked in registers until the staging tile is free -- the second pass's z registers are not live yet.  The
+  // depthwise taps then come from LDS: a global load inside the pass would make its s_waitcnt wait for the whole burst (in-order vmcnt).
+#ifndef EDTTS_DS_BURST
+#define EDTTS_DS_BURST 1
+#endif
+  constexpr bool BURST = EDTTS_DS_BURST && TP == kDfTWide;
+  constexpr int SEG = (kDfXld + 63) / 64;
+  constexpr int NB = (Cip + 2 * kDfWaves - 1) / (2 * kDfWaves);
+  float* dws = xs + Cip * kDfXld;        // [Cip][kDfTapLd] depthwise taps (BURST)
+  float vrow[BURST ? NB : 1][2][SEG];
+  auto rows_request = [&](int p) {
+    const int t0 = p * kDfT * stride - pad;
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int ci = wave + (2 * i + h) * kDfWaves;
+        const float* xr = x + ((size_t)b * Ci + (ci < Ci ? ci : 0)) * T;  // (wave-uniform)
+#pragma unroll
+        for (int u = 0; u < SEG; ++u) {
+          const int tl = lane + 64 * u, ts = t0 + tl;
+          vrow[BURST ? i : 0][h][u] = ((EDTTS_DS_ABL & 8) == 0 && ci < Ci && tl < nin && ts >= 0 && ts < T) ? xr[ts] : 0.f;
+        }
+      }
+  };
+  auto rows_park = [&]() {
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int ci = wave + (2 * i + h) * kDfWaves;
+#pragma unroll
+        for (int u = 0; u < SEG; ++u) {
+          const int tl = lane + 64 * u;
+          if (ci < Cip && tl < kDfXld) xs[ci * kDfXld + tl] = vrow[BURST ? i : 0][h][u];
+        }
+      }
+  };
+  DS_STAMP(0);
+#ifdef EDTTS_DS_STAMPS
+  if (threadIdx.x == 0) g_ds_stamps[blockIdx.x * 16 + 14] = __builtin_amdgcn_s_memrealtime();  // (100 MHz, one counter for the whole chip)
+#endif
+  if constexpr (BURST) {
+    rows_request(0);
+    for (int i = threadIdx.x; i < Cip * kDfTapLd; i += kDfThreads) {
+      const int ci = i / kDfTapLd, j = i % kDfTapLd;
+      dws[i] = (ci < Ci && j < ks) ? dw[ci * ks + j] : 0.f;
+    }
+  }
   f4 acc[CT][NP];  // lane (fq, g): channel 16 ct + fq, frames 128 p + 16 wave + 4 g + r
 #pragma unroll
   for (int ct = 0; ct < CT; ++ct)
@@ -1505,9 +1564,14 @@ __global__ __launch_bounds__(TP * 4) void k_dsconv_fused(const float* __restrict
     const int tb = p * kDfT;
     if (tb >= To) break;  // (uniform)
     if (p) __syncthreads();  // the previous pass has been read
-    {  // raw rows of this pass: wave w stages channels w, w + 8, ...; a row is 5 wave-contiguous loads along time, two rows per batch
+    if constexpr (BURST) {
+      rows_park();
+      DS_STAMP(1 + 4 * p);
+      __syncthreads();  // (also covers the weight and tap tiles on the first pass)
+      DS_STAMP(2 + 4 * p);
+      if (p + 1 < NP && (p + 1) * kDfT < To) rows_request(p + 1);
+    } else {  // raw rows of this pass: wave w stages channels w, w + 8, ...; a row is 5 wave-contiguous loads along time, two rows per batch
       const int t0 = tb * stride - pad;
-      constexpr int SEG = (kDfXld + 63) / 64;
       for (int c0 = wave; c0 < Cip; c0 += 2 * kDfWaves) {
         float v[2][SEG];
 #pragma unroll
@@ -1530,8 +1594,8 @@ __global__ __launch_bounds__(TP * 4) void k_dsconv_fused(const float* __restrict
           }
         }
       }
+      __syncthreads();  // (also covers the weight tile on the first pass)
     }
-    __syncthreads();  // (also covers the weight tile on the first pass)
     f4 at[KT];  // A operand = depthwise output: rows = this wave's 16 frames (lane fq), k = input channel 16 kt + 4 g + r
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt) at[kt] = splat(0.f);
@@ -1544,9 +1608,11 @@ __global__ __launch_bounds__(TP * 4) void k_dsconv_fused(const float* __restrict
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int ci = 16 * kt + 4 * g + r;
-          at[kt][r] = fmaf(xs[ci * kDfXld + (16 * wave + fq) * stride + j], dw[(ci < Ci ? ci : 0) * ks + j], at[kt][r]);
+          const float tap = BURST ? dws[ci * kDfTapLd + j] : dw[(ci < Ci ? ci : 0) * ks + j];
+          at[kt][r] = fmaf(xs[ci * kDfXld + (16 * wave + fq) * stride + j], tap, at[kt][r]);
         }
     }
+    DS_STAMP(3 + 4 * p);
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
       if (16 * ct >= Co) break;  // (uniform)
@@ -1561,6 +1627,7 @@ __global__ __launch_bounds__(TP * 4) void k_dsconv_fused(const float* __restrict
       }
     }
   }
+  DS_STAMP(9);
   // z = acc + bias
 #pragma unroll
   for (int ct = 0; ct < CT; ++ct) {
@@ -1572,10 +1639,16 @@ __global__ __launch_bounds__(TP * 4) void k_dsconv_fused(const float* __restrict
   // ---- GroupNorm statistics, deterministic order ----
   float* wsum = xs;                          // [waves][16 CT]
   float* chs = xs + kDfWaves * 16 * CT;      // [16 CT] per-channel totals
-  float* gst = chs + 16 * CT;                // [groups][2]: mean, rstd
+  float* gst = chs + 16 * CT;                // [groups][2]: mean, rstd (groups <= C_out <= 16 CT)
+  float* gws = gst + 2 * 16 * CT;            // [2][16 CT] GroupNorm weight, bias: read from LDS in the store phase -- a global load there makes
+                                             // every channel tile wait for the previous tile's stores (in-order vmcnt)
   auto channel_reduce = [&](auto centred_tag) {
     constexpr bool centred = decltype(centred_tag)::value;  // (compile-time: the plain-sum pass must not carry the centring arithmetic)
     __syncthreads();  // xs / wsum free
+    if (!centred && threadIdx.x < 16 * CT) {
+      gws[threadIdx.x] = threadIdx.x < Co ? gw[threadIdx.x] : 0.f;
+      gws[16 * CT + threadIdx.x] = threadIdx.x < Co ? gb[threadIdx.x] : 0.f;
+    }
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
       const int co = 16 * ct + fq;
@@ -1621,7 +1694,9 @@ __global__ __launch_bounds__(TP * 4) void k_dsconv_fused(const float* __restrict
     __syncthreads();
   } else {
     channel_reduce(std::integral_constant<bool, false>{});
+    DS_STAMP(10);
     channel_reduce(std::integral_constant<bool, true>{});
+    DS_STAMP(11);
   }
   // ---- y = GELU(GroupNorm(z)): 16-byte stores where the row allows it ----
   const bool vec = (To & 3) == 0;
@@ -1631,7 +1706,7 @@ __global__ __launch_bounds__(TP * 4) void k_dsconv_fused(const float* __restrict
   for (int ct = 0; ct < CT; ++ct) {
     const int co = 16 * ct + fq_e;
     if (co >= Co) continue;
-    const float mu = gst[2 * (co / cpg)], rs = gst[2 * (co / cpg) + 1], w = gw[co], bb = gb[co];
+    const float mu = gst[2 * (co / cpg)], rs = gst[2 * (co / cpg) + 1], w = gws[co], bb = gws[16 * CT + co];
     float* yr = y + ((size_t)b * Co + co) * To;
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
@@ -1652,6 +1727,328 @@ __global__ __launch_bounds__(TP * 4) void k_dsconv_fused(const float* __restrict
     }
     __builtin_amdgcn_sched_barrier(0);  // one channel tile at a time (the z tile leaves no registers for hoisted work)
   }
+  DS_STAMP(12);
+#ifdef EDTTS_DS_STAMPS
+  __builtin_amdgcn_s_waitcnt(0);
+  DS_STAMP(13);
+  if (threadIdx.x == 0) g_ds_stamps[blockIdx.x * 16 + 15] = __builtin_amdgcn_s_memrealtime();
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Group-pipelined form of the fused kernel (round 4), for the layer the reference builds (conv.py:47-48: GroupNorm(min(8, C_out))
+// -> C_out = 160: 8 groups of 20 channels; stride 1, ksize <= 5).  k_dsconv_fused holds the whole z tile until the statistics of
+// ALL groups are known, so every byte of y is stored in the last 5 us of a block's 53 (s_memrealtime stamps, scratch/ds_stamps.py)
+// and the kernel then waits 10 us for 84 MB of dirty lines to reach HBM.  GroupNorm groups are independent, though.  Here a wave
+// first computes the depthwise output of its 2 x 16 frames for all input channels (the MFMA A operand: 40 registers), then walks the
+// output-channel tiles in order: as soon as the last tile of a group has been computed, its statistics are taken (two block-wide
+// sums through LDS: mean, then the centred squares -- as accurate as the reference's two-pass GroupNorm, fixed order) and every tile
+// whose groups are complete is normalised, activated and STORED while the MFMAs of the next tile run; the halves of the next tile's
+// MFMAs sit between a partial-sum write and its barrier so that the barriers do not idle the matrix pipe.  At most three z tiles
+// (24 registers) are live.  Same shape limits as the sixteen-wave fused form, plus C_out == 16 CT and groups == 16 CT / CPG.
+// ---------------------------------------------------------------------------------------------------------
+template <int KT, int CT>
+constexpr int dsconv_grouped_lds_floats(int ng) { return dsconv_fused_lds_floats<KT, CT>() + 3 * 16 * CT + ng * 2 * (kDfTWide / 16); }
+template <int I, int N, class F>
+EDTTS_DEV void dsg_static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    dsg_static_for<I + 1, N>(f);
+  }
+}
+template <int CPG, int NG>
+constexpr int dsg_first_completing(int t) {
+  for (int grp = 0; grp < NG; ++grp)
+    if ((CPG * grp + CPG - 1) / 16 == t) return grp;
+  return -1;
+}
+template <int CTRL>
+EDTTS_DEV float dpp_add(float v) {  // v + (v of the lane the DPP control selects), inside a row of 16 lanes
+  return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+EDTTS_DEV float row_sum16(float v) {  // over the 16 lanes of a DPP row, the same value (bitwise) in all of them
+  v = dpp_add<0xB1>(v);
+  v = dpp_add<0x4E>(v);
+  v = dpp_add<0x141>(v);
+  return dpp_add<0x140>(v);
+}
+EDTTS_DEV float wave_sum64(float v) {  // over all 64 lanes, the same value (bitwise) in every lane; no LDS round trips (ds_bpermute)
+  v = group_sum(v);        // the four lane groups
+  v = dpp_add<0xB1>(v);    // quad_perm [1,0,3,2]: lane ^ 1
+  v = dpp_add<0x4E>(v);    // quad_perm [2,3,0,1]: lane ^ 2
+  v = dpp_add<0x141>(v);   // row_half_mirror: the other quad of the half row (the quads are uniform by now)
+  v = dpp_add<0x140>(v);   // row_mirror: the other half row
+  return v;
+}
+template <int KT, int CT, int CPG>
+__global__ __launch_bounds__(kDfTWide * 4) void k_dsconv_grouped(const float* __restrict__ x, const float* __restrict__ dw, const float* __restrict__ pw,
+                                                                  const float* __restrict__ pb, const float* __restrict__ gw, const float* __restrict__ gb,
+                                                                  int Ci, int T, int To, int ks, float* __restrict__ y) {
+  extern __shared__ __attribute__((aligned(16))) float dsm_all[];
+  constexpr int TP = kDfTWide, NP = 2, WAVES = TP / 16, THREADS = 64 * WAVES, Cip = 16 * KT, WLD = Cip + 4, Co = 16 * CT, NG = Co / CPG;
+  static_assert(Co % CPG == 0 && CPG >= 16 && CPG % 4 == 0, "a channel tile meets at most two groups");
+  float* wsm = dsm_all;                  // [Co][WLD] pointwise weights (columns >= Ci zero)
+  float* xs = wsm + Co * WLD;            // [Cip][kDfXld] raw input frames of the current pass
+  float* dws = xs + Cip * kDfXld;        // [Cip][kDfTapLd] depthwise taps
+  float* chp = dws + Cip * kDfTapLd;     // [3][Co] pointwise bias, GroupNorm weight, GroupNorm bias
+  float* part = chp + 3 * Co;            // [NG][2][WAVES] per-wave partial sums: plain, centred squares
+  const int b = blockIdx.x, pad = ks / 2;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fq = lane & 15, g = lane >> 4;
+  const int nin = TP - 1 + ks;
+  constexpr int SEG = (kDfXld + 63) / 64, NB = (Cip + 2 * WAVES - 1) / (2 * WAVES);
+  float vrow[NB][2][SEG];
+  auto rows_request = [&](int p) {
+    const int t0 = p * TP - pad;
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        if ((2 * i + h) * WAVES >= Cip) continue;  // (compile-time: past the last channel for every wave)
+        const int ci = wave + (2 * i + h) * WAVES;
+        const float* xr = x + ((size_t)b * Ci + (ci < Ci ? ci : 0)) * T;  // (wave-uniform)
+#pragma unroll
+        for (int u = 0; u < SEG; ++u) {
+          const int tl = lane + 64 * u, ts = t0 + tl;
+          vrow[i][h][u] = (ci < Ci && tl < nin && ts >= 0 && ts < T) ? xr[ts] : 0.f;
+        }
+      }
+  };
+  auto rows_park = [&]() {
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        if ((2 * i + h) * WAVES >= Cip) continue;
+        const int ci = wave + (2 * i + h) * WAVES;
+#pragma unroll
+        for (int u = 0; u < SEG; ++u) {
+          const int tl = lane + 64 * u;
+          if (ci < Cip && tl < kDfXld) xs[ci * kDfXld + tl] = vrow[i][h][u];
+        }
+      }
+  };
+  DS_STAMP(0);
+#ifdef EDTTS_DS_STAMPS
+  if (threadIdx.x == 0) g_ds_stamps[blockIdx.x * 16 + 14] = __builtin_amdgcn_s_memrealtime();
+#endif
+  rows_request(0);
+  {  // pointwise weights: all of a thread's loads in flight at once (as a loop of load -> LDS store round trips this took 5 us)
+    constexpr int NWV = (Co * Cip + THREADS - 1) / THREADS;
+    float wv[NWV];
+#pragma unroll
+    for (int k = 0; k < NWV; ++k) {
+      const int i = threadIdx.x + k * THREADS, co = i / Cip, ci = i % Cip;
+      wv[k] = (i < Co * Cip && ci < Ci) ? pw[(size_t)co * Ci + ci] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < NWV; ++k) {
+      const int i = threadIdx.x + k * THREADS, co = i / Cip, ci = i % Cip;
+      if (i < Co * Cip) wsm[co * WLD + ci] = wv[k];
+    }
+  }
+  for (int i = threadIdx.x; i < Cip * kDfTapLd; i += THREADS) {
+    const int ci = i / kDfTapLd, j = i % kDfTapLd;
+    dws[i] = (ci < Ci && j < ks) ? dw[ci * ks + j] : 0.f;
+  }
+  if (threadIdx.x < Co) {
+    chp[threadIdx.x] = pb[threadIdx.x];
+    chp[Co + threadIdx.x] = gw[threadIdx.x];
+    chp[2 * Co + threadIdx.x] = gb[threadIdx.x];
+  }
+  // ---- depthwise output of this wave's frames (rows fq of pass p: frame TP p + 16 wave + fq), all input channels; the first PRE channel
+  // tiles' MFMAs of pass 0 run while the rows of pass 1 are in flight ----
+  constexpr int PRE = 2;
+  const int tbase = 16 * wave + 4 * g;
+  f4 at[NP][KT];  // A operand: k = input channel 16 kt + 4 g + r
+  f4 acc[CT][NP];  // lane (fq, g) of tile t: channel 16 t + fq, frames TP p + 16 wave + 4 g + r
+  auto taps = [&](int p) {
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) at[p][kt] = splat(0.f);
+    for (int j = 0; j < ks; ++j) {  // Conv1d(padding = k/2), layers/conv.py:33-41; tap loop outermost (see k_dsconv_fused)
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int ci = 16 * kt + 4 * g + r;
+          at[p][kt][r] = fmaf(xs[ci * kDfXld + 16 * wave + fq + j], dws[ci * kDfTapLd + j], at[p][kt][r]);
+        }
+    }
+    if (TP * p + 16 * wave + fq >= To) {  // rows past the last output frame feed zeros: z there is exactly the bias (see lane_sum)
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt) at[p][kt] = splat(0.f);
+    }
+  };
+  auto chain = [&](int t, int p) {  // one pass of tile t: bias as the accumulator input
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+      const f4 w = *reinterpret_cast<const f4*>(wsm + (16 * t + fq) * WLD + 16 * kt + 4 * g);  // B operand: column = channel 16 t + fq
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[t][p] = EDTTS_MFMA(at[p][kt][r], w[r], acc[t][p]);
+    }
+  };
+  rows_park();
+  __syncthreads();  // (also covers the weight, tap and per-channel tiles)
+  DS_STAMP(12);
+  if (TP < To) rows_request(1);
+  taps(0);
+#pragma unroll
+  for (int t = 0; t < PRE; ++t) {
+    acc[t][0] = acc[t][1] = splat(chp[16 * t + fq]);
+    chain(t, 0);
+  }
+  if (TP < To) {  // (uniform)
+    __syncthreads();  // pass 0 has been read
+    rows_park();
+    __syncthreads();
+    taps(1);
+#pragma unroll
+    for (int t = 0; t < PRE; ++t) chain(t, 1);
+  } else {
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) at[1][kt] = splat(0.f);
+  }
+  DS_STAMP(1);
+  auto tile_mfma = [&](int t) {  // two independent accumulator chains (the passes), interleaved
+    __builtin_amdgcn_sched_barrier(0);  // (its weight fragments must not be hoisted over the store / statistics code before it: 20 registers)
+    const float bias = chp[16 * t + fq];
+    acc[t][0] = acc[t][1] = splat(bias);  // bias as the accumulator input
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+      const f4 w = *reinterpret_cast<const f4*>(wsm + (16 * t + fq) * WLD + 16 * kt + 4 * g);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        acc[t][0] = EDTTS_MFMA(at[0][kt][r], w[r], acc[t][0]);
+        if (TP < To) acc[t][1] = EDTTS_MFMA(at[1][kt][r], w[r], acc[t][1]);  // (uniform)
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  // Frames of this lane past To (only when To is not a multiple of 4 x 16-frame rows): their z is exactly the channel's bias (zero A rows),
+  // so the sums run over all eight values unmasked and the bias terms are taken out again.
+  float n_inv = 0.f;
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    const int over = TP * p + tbase + 4 - To;
+    n_inv += (float)(over < 0 ? 0 : (over > 4 ? 4 : over));
+  }
+  // sums over this lane's frames of tile t if the lane's channel belongs to group grp, else 0: z, or (z - m)^2
+  // (a lane without any valid frame contributes exactly 0, not the rounding residue of eight bias terms added and taken out again:
+  // with T = 1 there are 1 200 such lanes beside 20 values)
+  const bool some_valid = n_inv < 8.f;
+  float s8[CT];  // this lane's sum over its frames of tile t (taken once per tile: a tile serves two groups)
+  auto lane_sum = [&](int t, int grp) {
+    const int c = 16 * t + fq;
+    return (some_valid && c >= CPG * grp && c < CPG * (grp + 1)) ? s8[t] : 0.f;
+  };
+  auto lane_sq = [&](int t, int grp, float m) {
+    const float db = chp[16 * t + fq] - m;
+    float sum = -n_inv * db * db;
+#pragma unroll
+    for (int p = 0; p < NP; ++p)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float d = acc[t][p][r] - m;
+        sum = fmaf(d, d, sum);
+      }
+    const int c = 16 * t + fq;
+    return (some_valid && c >= CPG * grp && c < CPG * (grp + 1)) ? sum : 0.f;
+  };
+  // frames of wave w (both passes) inside [0, To)
+  auto wave_frames_in = [&](int w) {
+    int n = 0;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const int left = To - (TP * p + 16 * w);
+      n += left < 0 ? 0 : (left > 16 ? 16 : left);
+    }
+    return n;
+  };
+  // (reciprocals once: an IEEE divide is ten instructions, and the statistics would run nineteen of them per group)
+  const float n_own = (float)(CPG * wave_frames_in(wave));
+  const float nw_lane = (float)(CPG * wave_frames_in(fq));  // values of wave fq (see the combine below)
+  const float inv_n_own = n_own > 0.f ? 1.0f / n_own : 0.f;
+  float mu_g[NG], rs_g[NG];  // (wave-uniform)
+  const float inv_n_el = 1.0f / (float)(CPG * To);
+  const bool vec = (To & 3) == 0;
+  auto store_tile = [&](int t) {
+    constexpr float kRsqrt2 = 0.70710678118654752440f;
+    const int c = 16 * t + fq, gl = 16 * t / CPG, gh = (16 * t + 15) / CPG;
+    const bool low = c < CPG * (gl + 1);
+    const float mu = low ? mu_g[gl] : mu_g[gh], rs = low ? rs_g[gl] : rs_g[gh], w = chp[Co + c], bb = chp[2 * Co + c];
+    float* yr = y + ((size_t)b * Co + c) * To;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const int t0 = TP * p + tbase;
+      f4 o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float v = (acc[t][p][r] - mu) * rs * w + bb;
+        o[r] = 0.5f * v * (1.0f + erf_as(v * kRsqrt2));  // F.gelu (erf form), conv.py:64
+      }
+      if (vec && t0 + 3 < To) stg4(yr + t0, o);
+      else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (t0 + r < To) yr[t0 + r] = o[r];
+      }
+    }
+  };
+  // (compile-time walk: every tile / group index below is a constant, so the live z tiles and the group statistics stay in registers)
+  // Statistics of a group with ONE block-wide exchange: every wave reduces its own frames to (sum, centred squares about its OWN mean),
+  // and the sixteen pairs are combined exactly (Chan, Golub & LeVeque: M2 = sum_w M2_w + n_w (mean_w - mean)^2) in a fixed order --
+  // as accurate as the reference's two passes.
+  dsg_static_for<0, CT>([&](auto tc) {
+    constexpr int t = decltype(tc)::value;
+    constexpr int gfirst = dsg_first_completing<CPG, NG>(t);  // first group whose last tile is t (-1: none)
+    if constexpr (t >= PRE && dsg_first_completing<CPG, NG>(t - 1) < 0) tile_mfma(t);  // (else issued before the walk, or under the previous step's barrier)
+    {
+      float sum = -n_inv * chp[16 * t + fq];
+#pragma unroll
+      for (int p = 0; p < NP; ++p)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sum += acc[t][p][r];
+      s8[t] = sum;
+    }
+    dsg_static_for<0, NG>([&](auto gc) {
+      constexpr int grp = decltype(gc)::value;
+      if constexpr ((CPG * grp + CPG - 1) / 16 == t) {  // groups whose last tile is t
+        constexpr int t_first = CPG * grp / 16;
+        float s = 0.f;
+        dsg_static_for<t_first, t + 1>([&](auto uc) { s += lane_sum(decltype(uc)::value, grp); });
+        s = wave_sum64(s);
+        const float m_own = s * inv_n_own;
+        float s2 = 0.f;
+        dsg_static_for<t_first, t + 1>([&](auto uc) { s2 += lane_sq(decltype(uc)::value, grp, m_own); });
+        s2 = wave_sum64(s2);
+        if (lane == 0) {
+          part[(grp * 2 + 0) * WAVES + wave] = m_own;
+          part[(grp * 2 + 1) * WAVES + wave] = s2;
+        }
+        if constexpr (t + 1 < CT && t + 1 >= PRE && grp == gfirst) tile_mfma(t + 1);  // the next tile's MFMAs under the barrier
+        __syncthreads();
+        // lane fq of every row takes wave fq's pair; two 16-lane DPP sums instead of two 16-term loops in every lane (fixed tree order)
+        static_assert(WAVES == 16, "one wave per lane of a DPP row");
+        const float mw = part[(grp * 2 + 0) * WAVES + fq], m2w = part[(grp * 2 + 1) * WAVES + fq];
+        const float mu = row_sum16(nw_lane * mw) * inv_n_el;
+        const float dm = mw - mu;
+        const float m2 = row_sum16(fmaf(nw_lane * dm, dm, m2w));
+        // (wave-uniform values: into SGPRs, or sixteen VGPRs stay live through the walk)
+        mu_g[grp] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(mu)));
+        rs_g[grp] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(rsqrtf(m2 * inv_n_el + 1e-5f))));  // GroupNorm eps (torch default), biased variance
+      }
+    });
+    // tiles whose last group has just been completed
+    dsg_static_for<0, t + 1>([&](auto uc) {
+      constexpr int tt = decltype(uc)::value;
+      if constexpr ((CPG * ((16 * tt + 15) / CPG) + CPG - 1) / 16 == t) store_tile(tt);
+    });
+    DS_STAMP(2 + t);
+  });
+#ifdef EDTTS_DS_STAMPS
+  __builtin_amdgcn_s_waitcnt(0);
+  DS_STAMP(13);
+  if (threadIdx.x == 0) g_ds_stamps[blockIdx.x * 16 + 15] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 // =========================================================================================================
@@ -2821,13 +3218,19 @@ int edtts_dsconv_forward(const float* x, const float* dw, const float* pw, const
     const int lds = dsconv_fused_lds_floats<5, 10>() * (int)sizeof(float);
     auto kern = k_dsconv_fused<5, 10, 4, kDfT>;
     auto kern_wide = k_dsconv_fused<5, 10, 2, kDfTWide>;
+    auto kern_grp = k_dsconv_grouped<5, 10, 20>;  // C_out = 160, GroupNorm(8): the layer conv.py builds
+    const int lds_grp = dsconv_grouped_lds_floats<5, 10>(8) * (int)sizeof(float);
     if (dev >= 0 && dev < 64 && !attr_done[dev]) {
       HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
       HIP_TRY(hipFuncSetAttribute((const void*)kern_wide, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+      HIP_TRY(hipFuncSetAttribute((const void*)kern_grp, hipFuncAttributeMaxDynamicSharedMemorySize, lds_grp));
       attr_done[dev] = true;
     }
     static const bool no_wide = [] { const char* e = getenv("EDTTS_DSCONV_WAVES8"); return e && e[0] == '1'; }();  // (A/B hook)
-    if (!no_wide && stride == 1 && kDfTWide - 1 + ksize <= kDfXld)  // (measured and rejected: taps read straight from global memory instead of the staging tile, 85 vs 77.5 us)
+    static const bool no_grp = [] { const char* e = getenv("EDTTS_DSCONV_NOGROUP"); return e && e[0] == '1'; }();  // (A/B hook)
+    if (!no_grp && !no_wide && C_out == 160 && groups == 8 && stride == 1 && kDfTWide - 1 + ksize <= kDfXld)
+      hipLaunchKernelGGL(kern_grp, dim3(B), dim3(kDfTWide * 4), lds_grp, st, x, dw, pw, pb, gn_w, gn_b, C_in, T, To, ksize, y);
+    else if (!no_wide && stride == 1 && kDfTWide - 1 + ksize <= kDfXld)  // (measured and rejected: taps read straight from global memory instead of the staging tile, 85 vs 77.5 us)
       hipLaunchKernelGGL(kern_wide, dim3(B), dim3(kDfTWide * 4), lds, st, x, dw, pw, pb, gn_w, gn_b, C_in, C_out, T, To, ksize, stride, groups, y);
     else
       hipLaunchKernelGGL(kern, dim3(B), dim3(kDfT * 4), lds, st, x, dw, pw, pb, gn_w, gn_b, C_in, C_out, T, To, ksize, stride, groups, y);

@@ -372,6 +372,30 @@ def test_dsconv_stride_and_both_paths(golden, monkeypatch):
     assert max_abs(a.cpu(), ref) < 2e-5
 
 
+def test_dsconv_group_pipelined_form_vs_oracle():
+    """The group-pipelined one-kernel form (C_out = 160, GroupNorm(8), stride 1 -- the layer conv.py:47-48 builds; k_dsconv_grouped)
+    against the CPU oracle on shapes its frame masks and pass structure must get right: T not a multiple of 4 (scalar stores, frames
+    past T_out inside a wave's rows), T below one pass, T = 1, fewer input channels than the padded 80, kernel 5, an input with a
+    large offset (the per-wave centred statistics must not cancel), and non-trivial GroupNorm weights."""
+    gen = torch.Generator().manual_seed(11)
+    for (B, ci, T, ks, shift) in [(3, 80, 301, 3, 0.0), (2, 56, 509, 5, 0.0), (2, 80, 7, 3, 0.0), (1, 80, 1, 3, 0.0), (2, 80, 256, 5, 0.0),
+                                  (2, 80, 260, 3, 50.0), (2, 17, 512, 1, 0.0)]:
+        m = DepthwiseSeparableConv(ci, 160, kernel_size=ks)
+        with torch.no_grad():
+            m.norm.weight.copy_(torch.randn(160, generator=gen))
+            m.norm.bias.copy_(torch.randn(160, generator=gen))
+            m.pointwise.bias.copy_(torch.randn(160, generator=gen))
+        x = torch.randn(B, ci, T, generator=gen) + shift
+        ref = O.dsconv_forward(x.double(), m.depthwise.weight.double(), m.pointwise.weight.double(), m.pointwise.bias.double(),
+                               m.norm.weight.double(), m.norm.bias.double(), m.groups).float()
+        ref32 = O.dsconv_forward(x, m.depthwise.weight, m.pointwise.weight, m.pointwise.bias, m.norm.weight, m.norm.bias, m.groups)
+        y = m.to(DEV)(x.to(DEV)).cpu()
+        assert y.shape == ref.shape
+        # (offset 50: z sits ~50 sigma away from zero and every fp32 evaluation loses digits there -- the bar is the fp32 oracle's own error)
+        tol = max(2e-5, 3.0 * max_abs(ref32, ref))
+        assert max_abs(y, ref) < tol, f"B={B} C_in={ci} T={T} k={ks} shift={shift}: {max_abs(y, ref):.3e} vs fp64, the fp32 oracle {max_abs(ref32, ref):.3e}"
+
+
 def test_forward_large_score_range():
     """Forces the deferred-max rescale branch of the attention kernels (taken when a later key chunk exceeds the softmax
     reference point by > 2^32): q/k projections scaled so that score ranges span hundreds of octaves, plus a spiked context
