@@ -17,7 +17,8 @@
  *   - return value: 0 on success, a negative EDTTS_ERR_* otherwise; edtts_last_error() returns a
  *     thread-local message for the last failing call.
  *   - environment switches, read once per process: EDTTS_SUBSTREAMS=1..8 (see edtts_set_substreams, default 4);
- *     EDTTS_DSCONV_UNFUSED=1 forces the three-kernel conv path.
+ *     EDTTS_DSCONV_UNFUSED=1 forces the three-kernel conv path; EDTTS_DSCONV_NOGROUP=1 / EDTTS_DSCONV_WAVES8=1 select the older
+ *     one-kernel forms (A/B hooks: same results within the layer's 1e-5).
  */
 #ifndef EDTTS_H_
 #define EDTTS_H_
@@ -222,6 +223,8 @@ int edtts_sample_inpaint(const EdttsDims* dims, const void* packed, void* worksp
  * the raw rows of one 128-frame pass must fit the kernel's staging tile) run as ONE kernel whose intermediate never leaves
  * registers, and scratch may be NULL; every other shape (stride 3, a large ksize, more channels or frames) takes a three-kernel
  * path and needs scratch of B*C_out*T_out + 2*B*groups floats -- a NULL scratch is then EDTTS_ERR_ARG.
+ * (Within the one-kernel class, the layer the reference constructs -- C_out = 160, groups = 8, stride 1, k <= 5 -- runs a
+ * group-pipelined form whose stores overlap its MFMAs; the contract is the same.)
  * edtts_dsconv_scratch_floats answers for a given shape: 0 (one kernel, no scratch) or that count. */
 int edtts_dsconv_scratch_floats(int B, int C_in, int C_out, int T, int ksize, int stride, int groups, size_t* out_floats);
 int edtts_dsconv_forward(const float* x, const float* dw, const float* pw, const float* pb, const float* gn_w,
