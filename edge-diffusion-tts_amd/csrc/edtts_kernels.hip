@@ -1476,12 +1476,31 @@ EDTTS_DEV float erf_as(float x) {
   const float r = fmaf(-p * t, e, 1.0f);
   return copysignf(r, x);
 }
+// F.gelu (erf form) in one piece: with erf(x) = sign(x) (1 - q(t) e^{-x^2}), t = 1 / (1 + 0.3275911 |x|) (erf_as above),
+// 0.5 v (1 + erf(v / sqrt 2)) = max(v, 0) - |v| g,  g = 0.5 q(t) e^{-v^2 / 2}: no sign transfer, no 1 + erf -- 12 VALU + rcp + exp2.
+EDTTS_DEV float gelu_as(float v) {
+  const float av = fabsf(v);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752440f, av, 1.0f));
+  float q = fmaf(0.5f * 1.061405429f, t, 0.5f * -1.453152027f);
+  q = fmaf(q, t, 0.5f * 1.421413741f);
+  q = fmaf(q, t, 0.5f * -0.284496736f);
+  q = fmaf(q, t, 0.5f * 0.254829592f);
+  const float e = fast_exp2(v * v * (-0.5f * 1.4426950408889634f));
+  return fmaf(-av, q * t * e, fmaxf(v, 0.f));
+}
 #ifdef EDTTS_DS_STAMPS  // diagnostic build (-DEDTTS_EXPERIMENTS): s_memtime of wave 0 of every block at the phase boundaries of k_dsconv_fused
 __device__ unsigned long long g_ds_stamps[1024 * 16];
 #define DS_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 1024) g_ds_stamps[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 extern "C" int edtts_debug_read_ds_stamps(unsigned long long* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_ds_stamps), sizeof(g_ds_stamps)); }
 #else
 #define DS_STAMP(i) do { } while (0)
+#endif
+#if defined(EDTTS_DS_STAMPS) && EDTTS_DS_STAMPS == 2  // sub-phases of ONE walk step (tile 3) of k_dsconv_grouped instead of the per-tile stamps
+#define DS_SUB(t, i) do { if ((t) == 3) DS_STAMP(i); } while (0)
+#define DS_TILE(t) do { } while (0)
+#else
+#define DS_SUB(t, i) do { } while (0)
+#define DS_TILE(t) DS_STAMP(2 + (t))
 #endif
 #ifndef EDTTS_DS_ABL
 #define EDTTS_DS_ABL 0   // timing ablations (-DEDTTS_EXPERIMENTS; results wrong): 1 no erf, 2 no stores, 4 no MFMAs, 8 no input staging, 16 no statistics
@@ -1780,7 +1799,7 @@ EDTTS_DEV float wave_sum64(float v) {  // over all 64 lanes, the same value (bit
   v = dpp_add<0x140>(v);   // row_mirror: the other half row
   return v;
 }
-template <int KT, int CT, int CPG>
+template <int KT, int CT, int CPG, bool VEC>  // VEC: T_out % 4 == 0 -- a lane's four frames are all inside or all outside: 16-byte stores, no scalar tail path
 __global__ __launch_bounds__(kDfTWide * 4) void k_dsconv_grouped(const float* __restrict__ x, const float* __restrict__ dw, const float* __restrict__ pw,
                                                                   const float* __restrict__ pb, const float* __restrict__ gw, const float* __restrict__ gb,
                                                                   int Ci, int T, int To, int ks, float* __restrict__ y) {
@@ -1873,7 +1892,7 @@ __global__ __launch_bounds__(kDfTWide * 4) void k_dsconv_grouped(const float* __
           at[p][kt][r] = fmaf(xs[ci * kDfXld + 16 * wave + fq + j], dws[ci * kDfTapLd + j], at[p][kt][r]);
         }
     }
-    if (TP * p + 16 * wave + fq >= To) {  // rows past the last output frame feed zeros: z there is exactly the bias (see lane_sum)
+    if (TP * p + 16 * wave + fq >= To) {  // rows past the last output frame feed zeros: their accumulators stay exactly 0 (see the statistics)
 #pragma unroll
       for (int kt = 0; kt < KT; ++kt) at[p][kt] = splat(0.f);
     }
@@ -1893,7 +1912,7 @@ __global__ __launch_bounds__(kDfTWide * 4) void k_dsconv_grouped(const float* __
   taps(0);
 #pragma unroll
   for (int t = 0; t < PRE; ++t) {
-    acc[t][0] = acc[t][1] = splat(chp[16 * t + fq]);
+    acc[t][0] = acc[t][1] = splat(0.f);  // (the pointwise bias joins in the statistics and in the epilogue's shift: no accumulator set-up)
     chain(t, 0);
   }
   if (TP < To) {  // (uniform)
@@ -1908,23 +1927,31 @@ __global__ __launch_bounds__(kDfTWide * 4) void k_dsconv_grouped(const float* __
     for (int kt = 0; kt < KT; ++kt) at[1][kt] = splat(0.f);
   }
   DS_STAMP(1);
+  const bool two_passes = TP < To;
   auto tile_mfma = [&](int t) {  // two independent accumulator chains (the passes), interleaved
     __builtin_amdgcn_sched_barrier(0);  // (its weight fragments must not be hoisted over the store / statistics code before it: 20 registers)
-    const float bias = chp[16 * t + fq];
-    acc[t][0] = acc[t][1] = splat(bias);  // bias as the accumulator input
+    acc[t][0] = acc[t][1] = splat(0.f);
+    f4 w[KT];
 #pragma unroll
-    for (int kt = 0; kt < KT; ++kt) {
-      const f4 w = *reinterpret_cast<const f4*>(wsm + (16 * t + fq) * WLD + 16 * kt + 4 * g);
+    for (int kt = 0; kt < KT; ++kt) w[kt] = *reinterpret_cast<const f4*>(wsm + (16 * t + fq) * WLD + 16 * kt + 4 * g);
+    if (two_passes) {  // (uniform; ONE branch per tile, not one per MFMA)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        acc[t][0] = EDTTS_MFMA(at[0][kt][r], w[r], acc[t][0]);
-        if (TP < To) acc[t][1] = EDTTS_MFMA(at[1][kt][r], w[r], acc[t][1]);  // (uniform)
-      }
+      for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          acc[t][0] = EDTTS_MFMA(at[0][kt][r], w[kt][r], acc[t][0]);
+          acc[t][1] = EDTTS_MFMA(at[1][kt][r], w[kt][r], acc[t][1]);
+        }
+    } else {
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[t][0] = EDTTS_MFMA(at[0][kt][r], w[kt][r], acc[t][0]);
     }
     __builtin_amdgcn_sched_barrier(0);
   };
-  // Frames of this lane past To (only when To is not a multiple of 4 x 16-frame rows): their z is exactly the channel's bias (zero A rows),
-  // so the sums run over all eight values unmasked and the bias terms are taken out again.
+  // Frames of this lane past To (only when To is not a multiple of the 16-frame rows): their accumulators are exactly 0 (zero A rows), so the
+  // sums run over all eight values unmasked and the terms of the invalid frames are taken out again.
   float n_inv = 0.f;
 #pragma unroll
   for (int p = 0; p < NP; ++p) {
@@ -1941,13 +1968,13 @@ __global__ __launch_bounds__(kDfTWide * 4) void k_dsconv_grouped(const float* __
     return (some_valid && c >= CPG * grp && c < CPG * (grp + 1)) ? s8[t] : 0.f;
   };
   auto lane_sq = [&](int t, int grp, float m) {
-    const float db = chp[16 * t + fq] - m;
-    float sum = -n_inv * db * db;
+    const float mb = m - chp[16 * t + fq];  // z - m = acc - (m - bias); frames past To: acc = 0 exactly
+    float sum = -n_inv * mb * mb;
 #pragma unroll
     for (int p = 0; p < NP; ++p)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float d = acc[t][p][r] - m;
+        const float d = acc[t][p][r] - mb;
         sum = fmaf(d, d, sum);
       }
     const int c = 16 * t + fq;
@@ -1969,12 +1996,11 @@ __global__ __launch_bounds__(kDfTWide * 4) void k_dsconv_grouped(const float* __
   const float inv_n_own = n_own > 0.f ? 1.0f / n_own : 0.f;
   float mu_g[NG], rs_g[NG];  // (wave-uniform)
   const float inv_n_el = 1.0f / (float)(CPG * To);
-  const bool vec = (To & 3) == 0;
   auto store_tile = [&](int t) {
-    constexpr float kRsqrt2 = 0.70710678118654752440f;
     const int c = 16 * t + fq, gl = 16 * t / CPG, gh = (16 * t + 15) / CPG;
     const bool low = c < CPG * (gl + 1);
-    const float mu = low ? mu_g[gl] : mu_g[gh], rs = low ? rs_g[gl] : rs_g[gh], w = chp[Co + c], bb = chp[2 * Co + c];
+    const float mu = low ? mu_g[gl] : mu_g[gh], rs = low ? rs_g[gl] : rs_g[gh];
+    const float sc = rs * chp[Co + c], sh = fmaf(chp[c] - mu, sc, chp[2 * Co + c]);  // (acc + bias - mu) rs w + b as one fma per value
     float* yr = y + ((size_t)b * Co + c) * To;
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
@@ -1982,11 +2008,11 @@ __global__ __launch_bounds__(kDfTWide * 4) void k_dsconv_grouped(const float* __
       f4 o;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float v = (acc[t][p][r] - mu) * rs * w + bb;
-        o[r] = 0.5f * v * (1.0f + erf_as(v * kRsqrt2));  // F.gelu (erf form), conv.py:64
+        o[r] = gelu_as(fmaf(acc[t][p][r], sc, sh));  // F.gelu (erf form), conv.py:64
       }
-      if (vec && t0 + 3 < To) stg4(yr + t0, o);
-      else {
+      if constexpr (VEC) {
+        if (t0 < To) stg4(yr + t0, o);
+      } else {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
           if (t0 + r < To) yr[t0 + r] = o[r];
@@ -2002,7 +2028,7 @@ __global__ __launch_bounds__(kDfTWide * 4) void k_dsconv_grouped(const float* __
     constexpr int gfirst = dsg_first_completing<CPG, NG>(t);  // first group whose last tile is t (-1: none)
     if constexpr (t >= PRE && dsg_first_completing<CPG, NG>(t - 1) < 0) tile_mfma(t);  // (else issued before the walk, or under the previous step's barrier)
     {
-      float sum = -n_inv * chp[16 * t + fq];
+      float sum = (8.f - n_inv) * chp[16 * t + fq];  // the bias of this lane's valid frames (frames past To: acc = 0 exactly)
 #pragma unroll
       for (int p = 0; p < NP; ++p)
 #pragma unroll
@@ -2013,10 +2039,12 @@ __global__ __launch_bounds__(kDfTWide * 4) void k_dsconv_grouped(const float* __
       constexpr int grp = decltype(gc)::value;
       if constexpr ((CPG * grp + CPG - 1) / 16 == t) {  // groups whose last tile is t
         constexpr int t_first = CPG * grp / 16;
+        DS_SUB(t, 2);
         float s = 0.f;
         dsg_static_for<t_first, t + 1>([&](auto uc) { s += lane_sum(decltype(uc)::value, grp); });
         s = wave_sum64(s);
         const float m_own = s * inv_n_own;
+        DS_SUB(t, 3);
         float s2 = 0.f;
         dsg_static_for<t_first, t + 1>([&](auto uc) { s2 += lane_sq(decltype(uc)::value, grp, m_own); });
         s2 = wave_sum64(s2);
@@ -2024,8 +2052,11 @@ __global__ __launch_bounds__(kDfTWide * 4) void k_dsconv_grouped(const float* __
           part[(grp * 2 + 0) * WAVES + wave] = m_own;
           part[(grp * 2 + 1) * WAVES + wave] = s2;
         }
+        DS_SUB(t, 4);
         if constexpr (t + 1 < CT && t + 1 >= PRE && grp == gfirst) tile_mfma(t + 1);  // the next tile's MFMAs under the barrier
+        DS_SUB(t, 5);
         __syncthreads();
+        DS_SUB(t, 6);
         // lane fq of every row takes wave fq's pair; two 16-lane DPP sums instead of two 16-term loops in every lane (fixed tree order)
         static_assert(WAVES == 16, "one wave per lane of a DPP row");
         const float mw = part[(grp * 2 + 0) * WAVES + fq], m2w = part[(grp * 2 + 1) * WAVES + fq];
@@ -2037,12 +2068,14 @@ __global__ __launch_bounds__(kDfTWide * 4) void k_dsconv_grouped(const float* __
         rs_g[grp] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(rsqrtf(m2 * inv_n_el + 1e-5f))));  // GroupNorm eps (torch default), biased variance
       }
     });
+    DS_SUB(t, 7);
     // tiles whose last group has just been completed
     dsg_static_for<0, t + 1>([&](auto uc) {
       constexpr int tt = decltype(uc)::value;
       if constexpr ((CPG * ((16 * tt + 15) / CPG) + CPG - 1) / 16 == t) store_tile(tt);
     });
-    DS_STAMP(2 + t);
+    DS_SUB(t, 8);
+    DS_TILE(t);
   });
 #ifdef EDTTS_DS_STAMPS
   __builtin_amdgcn_s_waitcnt(0);
@@ -3218,12 +3251,13 @@ int edtts_dsconv_forward(const float* x, const float* dw, const float* pw, const
     const int lds = dsconv_fused_lds_floats<5, 10>() * (int)sizeof(float);
     auto kern = k_dsconv_fused<5, 10, 4, kDfT>;
     auto kern_wide = k_dsconv_fused<5, 10, 2, kDfTWide>;
-    auto kern_grp = k_dsconv_grouped<5, 10, 20>;  // C_out = 160, GroupNorm(8): the layer conv.py builds
+    auto kern_grp = (To & 3) == 0 ? k_dsconv_grouped<5, 10, 20, true> : k_dsconv_grouped<5, 10, 20, false>;  // C_out = 160, GroupNorm(8): the layer conv.py builds
     const int lds_grp = dsconv_grouped_lds_floats<5, 10>(8) * (int)sizeof(float);
     if (dev >= 0 && dev < 64 && !attr_done[dev]) {
       HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
       HIP_TRY(hipFuncSetAttribute((const void*)kern_wide, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-      HIP_TRY(hipFuncSetAttribute((const void*)kern_grp, hipFuncAttributeMaxDynamicSharedMemorySize, lds_grp));
+      HIP_TRY(hipFuncSetAttribute((const void*)k_dsconv_grouped<5, 10, 20, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_grp));
+      HIP_TRY(hipFuncSetAttribute((const void*)k_dsconv_grouped<5, 10, 20, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_grp));
       attr_done[dev] = true;
     }
     static const bool no_wide = [] { const char* e = getenv("EDTTS_DSCONV_WAVES8"); return e && e[0] == '1'; }();  // (A/B hook)

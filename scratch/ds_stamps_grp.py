@@ -18,11 +18,12 @@ rt0, rt1 = st[:, 14], st[:, 15]
 life = np.median(rt1 - rt0) * 0.01
 ticks = np.median(st[:, 13] - st[:, 0])
 print(f"block lifetime (s_memrealtime) median {life:.2f} us; shader clock {ticks / life:.0f} MHz; first start -> last end {(rt1.max() - rt0.min()) * 0.01:.2f} us; start spread {(rt0.max() - rt0.min()) * 0.01:.2f} us")
-names = ["start", "depthwise done"] + [f"tile {t} step" for t in range(10)] + ["(pass 0 parked)", "stores acked"]
+SUB = os.environ.get("DS_SUB", "0") == "1"  # a -DEDTTS_DS_STAMPS=2 build: sub-phases of the step of tile 3
+names = ["start", "depthwise done", "t3: step start (tile 3 MFMAs issued earlier)", "t3: sum + wave reduce", "t3: squares + wave reduce + LDS write", "t3: tile 4 MFMAs issued", "t3: barrier passed", "t3: combine done", "t3: tile stored (erf, 8 values)", None, None, None, None, "stores acked"] if SUB else ["start", "depthwise done"] + [f"tile {t} step" for t in range(10)] + ["(pass 0 parked)", "stores acked"]
 rel = (st - st[:, :1]) / (ticks / life)
 prev = 0.0
 for i, n in enumerate(names):
     if n is None: continue
     med = float(np.median(rel[:, i]))
-    print(f"{n:>16}: {med:7.2f} us (+{med - prev:5.2f})")
+    print(f"{n:>48}: {med:7.2f} us (+{med - prev:5.2f})")
     prev = med
