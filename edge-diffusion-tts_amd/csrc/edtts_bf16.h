@@ -619,6 +619,17 @@ EDTTS_DEV void attention16(QF&& qf, const __bf16* __restrict__ Kb, const __bf16*
     }
   };
   prefetch(0);
+  // EDTTS16_MFMA_SUM (round 4): the softmax row sums come out of the matrix pipe -- one more MFMA per head and query tile and step with an
+  // all-ones A operand leaves sum_k P[k][query] in every C/D register of the lane's query -- instead of 8 v_add per head and tile (the
+  // partial sums and their accumulation) plus the sum-based rescale test; the test reads the scores' maximum (v_max3 chains) instead.
+  // The step is bound by its VALU issue, the MFMA pipe idles three quarters of it.  The sums are those of the bf16-rounded P the P V
+  // product itself uses.
+#ifndef EDTTS16_MFMA_SUM
+#define EDTTS16_MFMA_SUM 1
+#endif
+  constexpr bool MSUM = EDTTS16_MFMA_SUM;
+  f4 ones_bits = as_f4(bf8{(__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f});
+  asm volatile("" : "+a"(ones_bits));  // four AGPRs for the life of the attention (an MFMA's A operand may be an AGPR)
   for (int hd = 0; hd < C::HEADS; hd += HP) {
     f4 O[HP][2][NF], lvec[HP][NF], NM[HP][NF];
     float nm[HP][NF];
@@ -676,7 +687,7 @@ EDTTS_DEV void attention16(QF&& qf, const __bf16* __restrict__ Kb, const __bf16*
         for (int t = 0; t < 2; ++t)
 #pragma unroll
           for (int r = 0; r < 4; ++r) P[h][t][ft][r] = fast_exp2(S[h][t][ft][r] - m);
-        ps[h][ft] = P[h][0][ft] + P[h][1][ft];
+        if constexpr (!MSUM) ps[h][ft] = P[h][0][ft] + P[h][1][ft];
       };
       if (first) {
 #pragma unroll
@@ -697,15 +708,32 @@ EDTTS_DEV void attention16(QF&& qf, const __bf16* __restrict__ Kb, const __bf16*
         const float lim = 4294967296.f;  // 2^32 (kDefer)
         // one test for the whole step: all probabilities are >= 0, so the sum over both heads and query tiles exceeds the limit
         // (or is not finite) whenever one row's does -- a false positive only moves reference points early
-        f4 tot = splat(0.f);
+        bool over;
+        if constexpr (MSUM) {
+          float mx = S[0][0][0][0];  // some score above its reference point by more than 32 octaves <=> some P > 2^32
 #pragma unroll
-        for (int h = 0; h < HP; ++h)
+          for (int h = 0; h < HP; ++h)
 #pragma unroll
-          for (int ft = 0; ft < NF; ++ft) {
-            exp_and_sum(h, ft, 0.f);
-            tot += ps[h][ft];
-          }
-        const bool over = !(hsum(tot) <= lim);
+            for (int ft = 0; ft < NF; ++ft) {
+              exp_and_sum(h, ft, 0.f);
+#pragma unroll
+              for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, S[h][t][ft][r]);
+            }
+          over = !(mx <= 32.f);
+          (void)lim;
+        } else {
+          f4 tot = splat(0.f);
+#pragma unroll
+          for (int h = 0; h < HP; ++h)
+#pragma unroll
+            for (int ft = 0; ft < NF; ++ft) {
+              exp_and_sum(h, ft, 0.f);
+              tot += ps[h][ft];
+            }
+          over = !(hsum(tot) <= lim);
+        }
         if (__any(over)) {
           // rare path (inputs through a volatile asm: see the single-head step)
           f4 T[HP][2][NF];
@@ -737,7 +765,7 @@ EDTTS_DEV void attention16(QF&& qf, const __bf16* __restrict__ Kb, const __bf16*
               for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) P[h][t][ft][r] = fast_exp2(T[h][t][ft][r] - dl);
-              ps[h][ft] = P[h][0][ft] + P[h][1][ft];
+              if constexpr (!MSUM) ps[h][ft] = P[h][0][ft] + P[h][1][ft];
             }
         }
       }
@@ -746,7 +774,7 @@ EDTTS_DEV void attention16(QF&& qf, const __bf16* __restrict__ Kb, const __bf16*
       for (int h = 0; h < HP; ++h)
 #pragma unroll
         for (int ft = 0; ft < NF; ++ft) {
-          lvec[h][ft] += ps[h][ft];
+          if constexpr (!MSUM) lvec[h][ft] += ps[h][ft];
           pb[h][ft] = pack8(P[h][0][ft], P[h][1][ft]);
         }
       if (hd == EDTTS_STAMP_HEAD) STAMPX16(stamps, sidx++);
@@ -756,6 +784,12 @@ EDTTS_DEV void attention16(QF&& qf, const __bf16* __restrict__ Kb, const __bf16*
         for (int ft = 0; ft < NF; ++ft)
 #pragma unroll
           for (int h = 0; h < HP; ++h) O[h][dt][ft] = EDTTS_MFMA16(VA[h][dt], pb[h][ft], O[h][dt][ft]);
+      if constexpr (MSUM) {
+#pragma unroll
+        for (int ft = 0; ft < NF; ++ft)
+#pragma unroll
+          for (int h = 0; h < HP; ++h) lvec[h][ft] = EDTTS_MFMA16(as_bf8(ones_bits), pb[h][ft], lvec[h][ft]);
+      }
 #pragma unroll
       for (int h = 0; h < HP; ++h) load_v(hd + h, cnext2, VA[h]);
       if (hd == EDTTS_STAMP_HEAD) STAMPX16(stamps, sidx++);
@@ -792,7 +826,7 @@ EDTTS_DEV void attention16(QF&& qf, const __bf16* __restrict__ Kb, const __bf16*
     for (int h = 0; h < HP; ++h)
 #pragma unroll
       for (int ft = 0; ft < NF; ++ft) {
-        const float lt = group_sum(hsum(lvec[h][ft]));
+        const float lt = MSUM ? lvec[h][ft][0] : group_sum(hsum(lvec[h][ft]));  // (MSUM: every C/D row holds the query's total)
         const float inv = lt > 0.f ? 1.0f / lt : 0.f;
         ob[h][ft] = pack8(O[h][0][ft] * inv, O[h][1][ft] * inv);
       }

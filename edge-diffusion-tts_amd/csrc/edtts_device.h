@@ -24,7 +24,7 @@
 #if !defined(EDTTS_EXPERIMENTS) && (                                                                                               \
     defined(EDTTS_ABLATE_QKVSTORES) || defined(EDTTS_ABLATE_KVLOADS) || defined(EDTTS_DIAG) || defined(EDTTS_KV2) ||                \
     defined(EDTTS_PERSIST) || defined(EDTTS_H_DMA) || defined(EDTTS_SPLITLOAD) || defined(EDTTS_STAMPS) || defined(EDTTS_DS_ABL) || \
-    defined(EDTTS_FAST_BUILD) || defined(EDTTS_W2) || defined(EDTTS_WAVELOG) || defined(EDTTS_PIN_MASK) || defined(EDTTS_HANDOVER) || defined(EDTTS_DS_BURST) || defined(EDTTS_DS_STAMPS) || defined(EDTTS_TAIL_RING2) || defined(EDTTS_RB) || defined(EDTTS_WMAX) ||        \
+    defined(EDTTS_FAST_BUILD) || defined(EDTTS_W2) || defined(EDTTS_WAVELOG) || defined(EDTTS_PIN_MASK) || defined(EDTTS_HANDOVER) || defined(EDTTS_DS_BURST) || defined(EDTTS16_MFMA_SUM) || defined(EDTTS_DS_STAMPS) || defined(EDTTS_TAIL_RING2) || defined(EDTTS_RB) || defined(EDTTS_WMAX) ||        \
     defined(EDTTS_NF_DEFAULT) || defined(EDTTS_NF_FFN) || defined(EDTTS_STAMP_THREAD) || defined(EDTTS_STAMP_HEAD) ||               \
     defined(EDTTS16_ABLATE_BARRIER) || defined(EDTTS16_ABLATE_DMA) || defined(EDTTS16_SPLIT_BUILD) || defined(EDTTS16_PHASES) ||    \
     defined(EDTTS16_NF) || defined(EDTTS16_CTX_F32) || defined(EDTTS16_WIDE_KD_SELF) || defined(EDTTS16_WIDE_KD) ||                 \
