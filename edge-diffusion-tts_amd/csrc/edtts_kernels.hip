@@ -1760,11 +1760,12 @@ __global__ __launch_bounds__(TP * 4) void k_dsconv_fused(const float* __restrict
 // ALL groups are known, so every byte of y is stored in the last 5 us of a block's 53 (s_memrealtime stamps, scratch/ds_stamps.py)
 // and the kernel then waits 10 us for 84 MB of dirty lines to reach HBM.  GroupNorm groups are independent, though.  Here a wave
 // first computes the depthwise output of its 2 x 16 frames for all input channels (the MFMA A operand: 40 registers), then walks the
-// output-channel tiles in order: as soon as the last tile of a group has been computed, its statistics are taken (two block-wide
-// sums through LDS: mean, then the centred squares -- as accurate as the reference's two-pass GroupNorm, fixed order) and every tile
-// whose groups are complete is normalised, activated and STORED while the MFMAs of the next tile run; the halves of the next tile's
-// MFMAs sit between a partial-sum write and its barrier so that the barriers do not idle the matrix pipe.  At most three z tiles
-// (24 registers) are live.  Same shape limits as the sixteen-wave fused form, plus C_out == 16 CT and groups == 16 CT / CPG.
+// output-channel tiles in order: as soon as the last tile of a group has been computed, its statistics are taken (every wave reduces
+// its own frames to a mean and the centred squares about it, ONE exchange of the sixteen pairs through LDS, exact combination in a
+// fixed order -- as accurate as the reference's two-pass GroupNorm, deterministic) and every tile whose groups are complete is
+// normalised, activated and STORED while the MFMAs of the next tile run: they are issued between the partial-sum write and its
+// barrier, so the barrier does not idle the matrix pipe.  At most three z tiles (24 registers) are live.  Same shape limits as the
+// sixteen-wave fused form, plus C_out == 16 CT and groups == 16 CT / CPG.  VEC: see the template parameter.
 // ---------------------------------------------------------------------------------------------------------
 template <int KT, int CT>
 constexpr int dsconv_grouped_lds_floats(int ng) { return dsconv_fused_lds_floats<KT, CT>() + 3 * 16 * CT + ng * 2 * (kDfTWide / 16); }
